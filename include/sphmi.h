@@ -1,0 +1,140 @@
+/* sphmi.h — C ABI of libsphmi.so, the MI355X (gfx950) PCISPH / Electrofluid step solver.
+ *
+ * Drop-in boundary: this library replaces the reference's C++ class `owOpenCLSolver`
+ * (/root/reference/src/owOpenCLSolver.h:28-62), which is the only seam between the step
+ * orchestrator owPhysicsFluidSimulator::simulationStep() (src/owPhysicsFluidSimulator.cpp:79-149)
+ * and the device kernels (src/sphFluid.cl). Each entry point names the reference member it replaces.
+ * Plain pointers and sizes only; no C++/torch types cross this boundary. All functions return
+ * 0 on success or a negative sph_status; nothing throws. sph_last_error() gives the text.
+ *
+ * The reference keeps its inputs in mutable globals (PARTICLE_COUNT, gridCells*, numOf*, delta, the
+ * box macros — owOpenCLSolver.h:14-17, owOpenCLSolver.cpp:7-23, owPhysicsConstant.h); here they are
+ * the explicit `sph_config`.
+ *
+ * After each sph_run_* the solver holds what the reference's buffers would hold after the same
+ * _run* call; sph_read_buffer() exports any of them in the reference's own
+ * layout and index space, so stage-by-stage parity can be checked. Internally the data is laid out
+ * for CDNA4, not as the reference's AoS buffers.
+ */
+#ifndef SPHMI_H
+#define SPHMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHMI_ABI_VERSION 1
+#define SPH_MAX_NEIGHBOR_COUNT 32 /* owOpenCLConstant.h:4 */
+#define SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE 7 /* owOpenCLConstant.h:6 */
+#define SPH_LIQUID_PARTICLE 1   /* owOpenCLConstant.h:8-10 */
+#define SPH_ELASTIC_PARTICLE 2
+#define SPH_BOUNDARY_PARTICLE 3
+
+typedef enum sph_status {
+  SPH_OK = 0,
+  SPH_ERR_INVALID = -1,  /* bad argument / configuration the kernels cannot represent */
+  SPH_ERR_HIP = -2,      /* a HIP runtime call failed (no GPU, out of memory, launch failure) */
+  SPH_ERR_ORDER = -3,    /* stage called before the stage it depends on */
+  SPH_ERR_UNKNOWN_BUFFER = -4,
+  SPH_ERR_SIZE = -5
+} sph_status;
+
+/* Everything the reference passes as kernel arguments or globals. Field names follow the reference. */
+typedef struct sph_config {
+  int32_t abi_version;      /* SPHMI_ABI_VERSION */
+  int32_t particleCount;    /* PARTICLE_COUNT */
+  int32_t gridCellsX, gridCellsY, gridCellsZ, gridCellCount; /* owOpenCLSolver.cpp:14-17 */
+  uint32_t cellIdMask;      /* 0xffff = reference behaviour (sphFluid.cl:229,377); 0xffffffff = wide */
+  float h, hashGridCellSize, hashGridCellSizeInv, simulationScale, simulationScaleInv; /* owPhysicsConstant.h:19-24 */
+  float xmin, xmax, ymin, ymax, zmin, zmax;                                           /* owOpenCLSolver.cpp:7-12 */
+  float r0, mass, rho0, timeStep, viscosity, delta;                                   /* owPhysicsConstant.h:12-27,63,75 */
+  float gravity_x, gravity_y, gravity_z;                                              /* owPhysicsConstant.h:72-74 */
+  float surfTensCoeff;      /* sphFluid.cl:662, evaluated once on the host in the reference's types */
+  double Wpoly6Coefficient, gradWspikyCoefficient, del2WviscosityCoefficient;         /* owPhysicsConstant.h:69-71 */
+  int32_t numOfElasticP;    /* rows of elasticConnectionsData */
+  int32_t elasticOffset;    /* numOfBoundaryP*(!generateInitialConfiguration), owOpenCLSolver.cpp:435 */
+  int32_t muscleCount;      /* MUSCLE_COUNT (owWorldSimulation.cpp:31) */
+  int32_t numOfMembranes;
+  int32_t maxIteration;     /* owPhysicsConstant.h:76 */
+  int32_t device;           /* HIP device ordinal */
+  void* stream;             /* hipStream_t to launch on; NULL = the solver creates its own */
+} sph_config;
+
+typedef struct sph_solver sph_solver;
+
+/* owOpenCLSolver::owOpenCLSolver(position_cpp, velocity_cpp, elasticConnectionsData_cpp, membraneData_cpp,
+ * particleMembranesList_cpp) — owOpenCLSolver.cpp:27-92. Host arrays are copied; the caller keeps ownership
+ * of all five (unlike the reference, particleMembranesList is NOT freed here). position/velocity: 4*N floats
+ * (x,y,z,type) / (vx,vy,vz,w); elastic: 4*32*numOfElasticP floats; membranes: 3*numOfMembranes ints;
+ * particleMembranesList: 7*numOfElasticP ints. */
+int sph_create(const sph_config* cfg, const float* position, const float* velocity, const float* elasticConnections,
+               const int32_t* membraneData, const int32_t* particleMembranesList, sph_solver** out);
+/* owOpenCLSolver::~owOpenCLSolver — owOpenCLSolver.cpp:744-748 */
+int sph_destroy(sph_solver* s);
+
+/* One per owOpenCLSolver::_run* (owOpenCLSolver.h:37-56, owOpenCLSolver.cpp:213-687), same order contract as
+ * simulationStep(). Asynchronous on the solver's stream. */
+int sph_run_clear_buffers(sph_solver* s);                          /* _runClearBuffers            :213 */
+int sph_run_hash_particles(sph_solver* s);                         /* _runHashParticles           :229 */
+int sph_run_sort(sph_solver* s);                                   /* _runSort (host qsort there) :255 */
+int sph_run_sort_post_pass(sph_solver* s);                         /* _runSortPostPass            :262 */
+int sph_run_indexx(sph_solver* s);                                 /* _runIndexx                  :284 */
+int sph_run_index_post_pass(sph_solver* s);                        /* _runIndexPostPass (host)    :305 */
+int sph_run_find_neighbors(sph_solver* s);                         /* _runFindNeighbors           :320 */
+int sph_run_pcisph_compute_density(sph_solver* s);                 /* _run_pcisph_computeDensity  :357 */
+int sph_run_pcisph_compute_forces_and_init_pressure(sph_solver* s);/* ..._computeForcesAndInitPressure :386 */
+int sph_run_pcisph_compute_elastic_forces(sph_solver* s);          /* ..._computeElasticForces    :420 */
+int sph_run_pcisph_predict_positions(sph_solver* s);               /* ..._predictPositions        :454 */
+int sph_run_pcisph_predict_density(sph_solver* s);                 /* ..._predictDensity          :490 */
+int sph_run_pcisph_correct_pressure(sph_solver* s);                /* ..._correctPressure         :519 */
+int sph_run_pcisph_compute_pressure_force_acceleration(sph_solver* s); /* ..._computePressureForceAcceleration :549 */
+int sph_run_pcisph_integrate(sph_solver* s, int iterationCount);   /* _run_pcisph_integrate       :649 */
+int sph_run_clear_membrane_buffers(sph_solver* s);                 /* _run_clearMembraneBuffers   :583 */
+int sph_run_compute_interaction_with_membranes(sph_solver* s);     /* _run_computeInteractionWithMembranes :602 */
+int sph_run_compute_interaction_with_membranes_finalize(sph_solver* s); /* ..._finalize           :628 */
+
+/* The whole stage sequence of owPhysicsFluidSimulator::simulationStep() (owPhysicsFluidSimulator.cpp:88-113) as one
+ * call on the solver's stream, with the fusions of DESIGN.md §4. Same results as calling the sph_run_* above in order. */
+int sph_step(sph_solver* s, int iterationCount);
+
+/* owOpenCLSolver::updateMuscleActivityData — owOpenCLSolver.cpp:738-742 (n must equal muscleCount) */
+int sph_update_muscles(sph_solver* s, const float* signal, int n);
+
+/* owOpenCLSolver::read_position_buffer / read_density_buffer / read_particleIndex_buffer — owOpenCLSolver.h:60-62.
+ * Blocking. position: 4N floats, orig order. density: N floats, SORTED order (as the reference).
+ * particleIndex: 2N uints (cell, origId), sorted. velocity has no reference getter; provided for checks. */
+int sph_read_position(sph_solver* s, float* out4N);
+int sph_read_velocity(sph_solver* s, float* out4N);
+int sph_read_density(sph_solver* s, float* outN);
+int sph_read_particle_index(sph_solver* s, uint32_t* out2N);
+
+/* Test/inspection export in the reference's layout. Names: position[2N f4] velocity[2N f4]
+ * sortedPosition[2N f4] sortedVelocity[N f4] acceleration[2N f4] neighborMap[32N f2] neighborIds[32N i32]
+ * particleIndex[N u2] particleIndexBack[N u32] gridCellIndex[G+1 u32] gridCellIndexFixedUp[G+1 u32]
+ * pressure[N f32] rho[2N f32]. `bytes` must equal the buffer's size (query with out == NULL: returns the size
+ * through *needed). Blocking. */
+int sph_read_buffer(sph_solver* s, const char* name, void* out, size_t bytes, size_t* needed);
+
+int sph_synchronize(sph_solver* s);
+
+/* Per-stage device timing with hipEvents on the solver's stream (the reference prints per-stage wall time,
+ * owPhysicsFluidSimulator.cpp:88-115). Stage ids = sph_stage. Times accumulate until reset. */
+typedef enum sph_stage {
+  SPH_ST_HASH = 0, SPH_ST_SORT, SPH_ST_SORT_POST, SPH_ST_INDEX, SPH_ST_FIND_NEIGHBORS, SPH_ST_DENSITY,
+  SPH_ST_FORCES, SPH_ST_ELASTIC, SPH_ST_PREDICT_DENSITY, SPH_ST_PRESSURE_FORCE, SPH_ST_INTEGRATE, SPH_ST_MEMBRANES,
+  SPH_ST_COUNT
+} sph_stage;
+int sph_set_stage_timing(sph_solver* s, int enable);
+int sph_get_stage_times(sph_solver* s, double* ms_total, int64_t* launches, int n); /* n = SPH_ST_COUNT */
+int sph_reset_stage_times(sph_solver* s);
+
+const char* sph_last_error(void);
+int sph_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHMI_H */

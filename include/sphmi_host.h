@@ -1,0 +1,50 @@
+/* sphmi_host.h — C ABI of libsphmi_host.so: the host-side pieces either side of the device path that the
+ * reference keeps in owPhysicsConstant.h, owOpenCLSolver.cpp:7-17, owPhysicsFluidSimulator.cpp:164-203 (calcDelta),
+ * owHelper.cpp (text loaders, boundary-shell generator) and main_sim.py (muscle signals). Pure C++/libm, no GPU.
+ */
+#ifndef SPHMI_HOST_H
+#define SPHMI_HOST_H
+
+#include "sphmi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Physics constants exactly as the reference's compiler evaluates them (owPhysicsConstant.h:12-76),
+ * delta from calcDelta (owPhysicsFluidSimulator.cpp:164-203), the shipped box 30h x 20h x 250h and its grid
+ * (owOpenCLSolver.cpp:7-17), cellIdMask = 0xffff, no elastic matter, muscleCount = 100, maxIteration = 3. */
+int sphmi_default_config(sph_config* cfg);
+
+/* Replace the box: maxima given in units of h as *double* multipliers, evaluated like the reference's macros
+ * `XMAX 30.0*h` (double product narrowed to float) and grid dims `(int)((MAX-MIN)/h)+1` (owOpenCLSolver.cpp:7-17). */
+int sphmi_config_set_box(sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, uint32_t cellIdMask);
+
+/* owHelper::preLoadConfiguration (owHelper.cpp:1431-1458): number of particles in a position file, -1 on error. */
+int sphmi_count_particles(const char* positionFile);
+/* owHelper::loadConfiguration (owHelper.cpp:1460-1545), position + velocity part. Returns 0 or negative. */
+int sphmi_load_configuration(const char* positionFile, const char* velocityFile, int count, float* position4N,
+                             float* velocity4N, int* numOfLiquidP, int* numOfElasticP, int* numOfBoundaryP);
+/* elasticconnections.txt reader (owHelper.cpp:1512-1540): rows of `jd rij0 val1 val2`; returns rows read. */
+int sphmi_load_elastic_connections(const char* file, int numOfElasticP, float* out4x32xE);
+
+/* Synthetic box of SURVEY §8(d): liquid lattice first, then the boundary shell exactly as
+ * owHelper::generateConfiguration stage 1 (owHelper.cpp:717-719,770-928; normals in `velocity`, type 3).
+ * Liquid: lx*ly*lz lattice, spacing `spacing`, origin (ox,oy,oz), type 1.1, zero velocity, optional uniform jitter
+ * in [-jitter, jitter] per axis from PCG32(seed). The box maxima are given again as the double multipliers of h,
+ * because the reference sizes the shell from the un-narrowed macros `XMAX 30.0*h` (owHelper.cpp:717-719).
+ * sphmi_box_counts gives the sizes to allocate. */
+int sphmi_box_counts(const sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, int lx, int ly, int lz,
+                     int* numOfLiquidP, int* numOfBoundaryP);
+int sphmi_generate_box(const sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, int lx, int ly, int lz,
+                       float spacing, float ox, float oy, float oz, float jitter, uint64_t seed, float* position4N,
+                       float* velocity4N);
+
+/* Muscle activation of main_sim.py:4-53 / PyramidalSimulation.cpp:68-93 in closed form:
+ * 96 values for step t, entries 96..muscleCount-1 left 0. */
+int sphmi_muscle_signal(int step, float* out, int muscleCount);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

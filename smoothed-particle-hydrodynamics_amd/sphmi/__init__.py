@@ -1,0 +1,340 @@
+"""sphmi — ctypes binding of libsphmi.so / libsphmi_host.so (include/sphmi.h, include/sphmi_host.h).
+
+`owHIPSolver` mirrors the reference's `owOpenCLSolver` (src/owOpenCLSolver.h:28-62) method for method, and
+`owPhysicsFluidSimulator` mirrors the stage order of `simulationStep()` (src/owPhysicsFluidSimulator.cpp:79-149),
+so tests read like calls into the reference. There is no CPU fallback: if libsphmi.so or a GPU is missing the
+constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libsphmi.so")
+HOST_LIB_PATH = os.path.join(_PKG, "libsphmi_host.so")
+
+ABI_VERSION = 1
+MAX_NEIGHBOR_COUNT = 32
+LIQUID_PARTICLE, ELASTIC_PARTICLE, BOUNDARY_PARTICLE = 1, 2, 3
+
+STAGE_NAMES = ["hash", "sort", "sort_post", "index", "find_neighbors", "density", "forces", "elastic",
+               "predict_density", "pressure_force", "integrate", "membranes"]
+
+
+class SphConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("particleCount", C.c_int32),
+                ("gridCellsX", C.c_int32), ("gridCellsY", C.c_int32), ("gridCellsZ", C.c_int32),
+                ("gridCellCount", C.c_int32), ("cellIdMask", C.c_uint32)] + \
+               [(n, C.c_float) for n in
+                ["h", "hashGridCellSize", "hashGridCellSizeInv", "simulationScale", "simulationScaleInv",
+                 "xmin", "xmax", "ymin", "ymax", "zmin", "zmax", "r0", "mass", "rho0", "timeStep", "viscosity",
+                 "delta", "gravity_x", "gravity_y", "gravity_z", "surfTensCoeff"]] + \
+               [(n, C.c_double) for n in ["Wpoly6Coefficient", "gradWspikyCoefficient", "del2WviscosityCoefficient"]] + \
+               [(n, C.c_int32) for n in ["numOfElasticP", "elasticOffset", "muscleCount", "numOfMembranes",
+                                         "maxIteration", "device"]] + \
+               [("stream", C.c_void_p)]
+
+
+class SphError(RuntimeError):
+    pass
+
+
+_host = None
+_dev = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise SphError("libsphmi_host.so not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.sphmi_default_config.argtypes = [C.POINTER(SphConfig)]
+        L.sphmi_config_set_box.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_uint32]
+        L.sphmi_count_particles.argtypes = [C.c_char_p]
+        L.sphmi_load_configuration.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sphmi_load_elastic_connections.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.sphmi_box_counts.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]
+        L.sphmi_generate_box.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.sphmi_muscle_signal.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        _host = L
+    return _host
+
+
+_STAGE_FUNCS = ["sph_run_clear_buffers", "sph_run_hash_particles", "sph_run_sort", "sph_run_sort_post_pass",
+                "sph_run_indexx", "sph_run_index_post_pass", "sph_run_find_neighbors",
+                "sph_run_pcisph_compute_density", "sph_run_pcisph_compute_forces_and_init_pressure",
+                "sph_run_pcisph_compute_elastic_forces", "sph_run_pcisph_predict_positions",
+                "sph_run_pcisph_predict_density", "sph_run_pcisph_correct_pressure",
+                "sph_run_pcisph_compute_pressure_force_acceleration", "sph_run_clear_membrane_buffers",
+                "sph_run_compute_interaction_with_membranes", "sph_run_compute_interaction_with_membranes_finalize"]
+EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sph_step", "sph_update_muscles",
+                    "sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index",
+                    "sph_read_buffer", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
+                    "sph_reset_stage_times", "sph_last_error", "sph_abi_version"] + _STAGE_FUNCS
+HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
+                         "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
+                         "sphmi_generate_box", "sphmi_muscle_signal"]
+
+
+def device_lib():
+    """Load libsphmi.so (the HIP solver). Raises if it has not been built — there is no fallback."""
+    global _dev
+    if _dev is None:
+        if not os.path.exists(LIB_PATH):
+            raise SphError("libsphmi.so not built: the HIP extension is required (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.sph_create.argtypes = [C.POINTER(SphConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_void_p)]
+        L.sph_destroy.argtypes = [C.c_void_p]
+        for f in _STAGE_FUNCS + ["sph_synchronize", "sph_reset_stage_times"]:
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.sph_run_pcisph_integrate.argtypes = [C.c_void_p, C.c_int]
+        L.sph_step.argtypes = [C.c_void_p, C.c_int]
+        L.sph_update_muscles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for f in ["sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index"]:
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.sph_read_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.sph_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
+        L.sph_get_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+        L.sph_last_error.restype = C.c_char_p
+        _dev = L
+    return _dev
+
+
+# ----------------------------------------------------------------------------- host helpers
+def default_config():
+    cfg = SphConfig()
+    rc = host_lib().sphmi_default_config(C.byref(cfg))
+    if rc:
+        raise SphError("sphmi_default_config failed: %d" % rc)
+    cfg._box_in_h = (30.0, 20.0, 250.0)  # owPhysicsConstant.h:32-37
+    return cfg
+
+
+def set_box(cfg, xmax_in_h, ymax_in_h, zmax_in_h, cell_id_mask=0xffff):
+    rc = host_lib().sphmi_config_set_box(C.byref(cfg), xmax_in_h, ymax_in_h, zmax_in_h, cell_id_mask)
+    if rc:
+        raise SphError("sphmi_config_set_box failed: %d" % rc)
+    cfg._box_in_h = (float(xmax_in_h), float(ymax_in_h), float(zmax_in_h))
+    return cfg
+
+
+def config_dict(cfg):
+    """sph_config as a dict with the oracle's key names (oracle/oraclebind.make_params)."""
+    d = {n: getattr(cfg, n) for n, _ in SphConfig._fields_ if n not in ("stream",)}
+    d["N"] = d["particleCount"]
+    return d
+
+
+def load_configuration(position_file, velocity_file):
+    """owHelper::preLoadConfiguration + loadConfiguration (owHelper.cpp:1431-1545)."""
+    n = host_lib().sphmi_count_particles(position_file.encode())
+    if n <= 0:
+        raise SphError("cannot read %s" % position_file)
+    pos = np.empty((n, 4), np.float32)
+    vel = np.empty((n, 4), np.float32)
+    nl, ne, nb = C.c_int(), C.c_int(), C.c_int()
+    rc = host_lib().sphmi_load_configuration(position_file.encode(), velocity_file.encode(), n, pos.ctypes.data,
+                                             vel.ctypes.data, C.byref(nl), C.byref(ne), C.byref(nb))
+    if rc:
+        raise SphError("sphmi_load_configuration failed: %d" % rc)
+    return pos, vel, dict(numOfLiquidP=nl.value, numOfElasticP=ne.value, numOfBoundaryP=nb.value)
+
+
+def generate_box(cfg, lx, ly, lz, spacing=None, origin=None, jitter=0.0, seed=20261004):
+    """Synthetic pure-liquid box of SURVEY §8(d): liquid lattice + reference boundary shell. Sets cfg.particleCount."""
+    nl, nb = C.c_int(), C.c_int()
+    bx = cfg._box_in_h
+    rc = host_lib().sphmi_box_counts(C.byref(cfg), bx[0], bx[1], bx[2], lx, ly, lz, C.byref(nl), C.byref(nb))
+    if rc:
+        raise SphError("sphmi_box_counts failed: %d" % rc)
+    n = nl.value + nb.value
+    r0 = np.float32(cfg.r0)
+    if spacing is None:
+        spacing = np.float32(0.93) * r0
+    if origin is None:
+        origin = (np.float32(3) * r0,) * 3
+    pos = np.empty((n, 4), np.float32)
+    vel = np.empty((n, 4), np.float32)
+    rc = host_lib().sphmi_generate_box(C.byref(cfg), bx[0], bx[1], bx[2], lx, ly, lz, spacing, origin[0], origin[1], origin[2], jitter,
+                                       seed, pos.ctypes.data, vel.ctypes.data)
+    if rc:
+        raise SphError("sphmi_generate_box failed: %d" % rc)
+    cfg.particleCount = n
+    return pos, vel, dict(numOfLiquidP=nl.value, numOfElasticP=0, numOfBoundaryP=nb.value)
+
+
+def muscle_signal(step, muscle_count=100):
+    out = np.zeros(muscle_count, np.float32)
+    rc = host_lib().sphmi_muscle_signal(step, out.ctypes.data, muscle_count)
+    if rc:
+        raise SphError("sphmi_muscle_signal failed: %d" % rc)
+    return out
+
+
+# ----------------------------------------------------------------------------- device solver
+_BUF_DTYPE = {"position": np.float32, "velocity": np.float32, "sortedPosition": np.float32,
+              "sortedVelocity": np.float32, "acceleration": np.float32, "neighborMap": np.float32,
+              "neighborIds": np.int32, "particleIndex": np.uint32, "particleIndexBack": np.uint32,
+              "gridCellIndex": np.uint32, "gridCellIndexFixedUp": np.uint32, "pressure": np.float32,
+              "rho": np.float32}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class owHIPSolver:
+    """Counterpart of owOpenCLSolver (src/owOpenCLSolver.h:28-62): same methods, backed by libsphmi.so."""
+
+    def __init__(self, cfg, position_cpp, velocity_cpp, elasticConnectionsData_cpp=None, membraneData_cpp=None,
+                 particleMembranesList_cpp=None):
+        self._L = device_lib()
+        self.cfg = cfg
+        self.N = cfg.particleCount
+        pos = np.ascontiguousarray(position_cpp, np.float32)
+        vel = np.ascontiguousarray(velocity_cpp, np.float32)
+        if pos.size != 4 * self.N or vel.size != 4 * self.N:
+            raise SphError("position/velocity must hold 4*particleCount floats")
+        el = None if elasticConnectionsData_cpp is None else np.ascontiguousarray(elasticConnectionsData_cpp, np.float32)
+        mb = None if membraneData_cpp is None else np.ascontiguousarray(membraneData_cpp, np.int32)
+        pm = None if particleMembranesList_cpp is None else np.ascontiguousarray(particleMembranesList_cpp, np.int32)
+        h = C.c_void_p()
+        self._chk(self._L.sph_create(C.byref(cfg), _ptr(pos), _ptr(vel), _ptr(el), _ptr(mb), _ptr(pm), C.byref(h)))
+        self._h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SphError("libsphmi: %s (status %d)" % (self._L.sph_last_error().decode(), rc))
+        return 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- owOpenCLSolver::_run* (owOpenCLSolver.h:37-56) ---
+    def _runClearBuffers(self): return self._chk(self._L.sph_run_clear_buffers(self._h))
+    def _runHashParticles(self): return self._chk(self._L.sph_run_hash_particles(self._h))
+    def _runSort(self): return self._chk(self._L.sph_run_sort(self._h))
+    def _runSortPostPass(self): return self._chk(self._L.sph_run_sort_post_pass(self._h))
+    def _runIndexx(self): return self._chk(self._L.sph_run_indexx(self._h))
+    def _runIndexPostPass(self): return self._chk(self._L.sph_run_index_post_pass(self._h))
+    def _runFindNeighbors(self): return self._chk(self._L.sph_run_find_neighbors(self._h))
+    def _run_pcisph_computeDensity(self): return self._chk(self._L.sph_run_pcisph_compute_density(self._h))
+    def _run_pcisph_computeForcesAndInitPressure(self): return self._chk(self._L.sph_run_pcisph_compute_forces_and_init_pressure(self._h))
+    def _run_pcisph_computeElasticForces(self): return self._chk(self._L.sph_run_pcisph_compute_elastic_forces(self._h))
+    def _run_pcisph_predictPositions(self): return self._chk(self._L.sph_run_pcisph_predict_positions(self._h))
+    def _run_pcisph_predictDensity(self): return self._chk(self._L.sph_run_pcisph_predict_density(self._h))
+    def _run_pcisph_correctPressure(self): return self._chk(self._L.sph_run_pcisph_correct_pressure(self._h))
+    def _run_pcisph_computePressureForceAcceleration(self): return self._chk(self._L.sph_run_pcisph_compute_pressure_force_acceleration(self._h))
+    def _run_pcisph_integrate(self, iterationCount): return self._chk(self._L.sph_run_pcisph_integrate(self._h, iterationCount))
+    def _run_clearMembraneBuffers(self): return self._chk(self._L.sph_run_clear_membrane_buffers(self._h))
+    def _run_computeInteractionWithMembranes(self): return self._chk(self._L.sph_run_compute_interaction_with_membranes(self._h))
+    def _run_computeInteractionWithMembranes_finalize(self): return self._chk(self._L.sph_run_compute_interaction_with_membranes_finalize(self._h))
+
+    def updateMuscleActivityData(self, signal):
+        s = np.ascontiguousarray(signal, np.float32)
+        return self._chk(self._L.sph_update_muscles(self._h, _ptr(s), s.size))
+
+    def read_position_buffer(self, out=None):
+        out = np.empty((self.N, 4), np.float32) if out is None else out
+        self._chk(self._L.sph_read_position(self._h, _ptr(out)))
+        return out
+
+    def read_velocity_buffer(self, out=None):
+        out = np.empty((self.N, 4), np.float32) if out is None else out
+        self._chk(self._L.sph_read_velocity(self._h, _ptr(out)))
+        return out
+
+    def read_density_buffer(self, out=None):
+        out = np.empty(self.N, np.float32) if out is None else out
+        self._chk(self._L.sph_read_density(self._h, _ptr(out)))
+        return out
+
+    def read_particleIndex_buffer(self, out=None):
+        out = np.empty((self.N, 2), np.uint32) if out is None else out
+        self._chk(self._L.sph_read_particle_index(self._h, _ptr(out)))
+        return out
+
+    # --- extras ---
+    def step(self, iterationCount=0):
+        """Fused fast path == the stage sequence of simulationStep()."""
+        return self._chk(self._L.sph_step(self._h, iterationCount))
+
+    def synchronize(self):
+        return self._chk(self._L.sph_synchronize(self._h))
+
+    def buffer(self, name):
+        need = C.c_size_t()
+        self._chk(self._L.sph_read_buffer(self._h, name.encode(), None, 0, C.byref(need)))
+        out = np.empty(need.value // np.dtype(_BUF_DTYPE[name]).itemsize, _BUF_DTYPE[name])
+        self._chk(self._L.sph_read_buffer(self._h, name.encode(), _ptr(out), need.value, None))
+        return out
+
+    def set_stage_timing(self, enable=True):
+        return self._chk(self._L.sph_set_stage_timing(self._h, int(enable)))
+
+    def reset_stage_times(self):
+        return self._chk(self._L.sph_reset_stage_times(self._h))
+
+    def stage_times(self):
+        n = len(STAGE_NAMES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        self._chk(self._L.sph_get_stage_times(self._h, ms, cnt, n))
+        return {STAGE_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+class owPhysicsFluidSimulator:
+    """Stage order of owPhysicsFluidSimulator::simulationStep() (owPhysicsFluidSimulator.cpp:79-149)."""
+
+    def __init__(self, cfg, position_cpp, velocity_cpp, elasticConnectionsData_cpp=None, membraneData_cpp=None,
+                 particleMembranesList_cpp=None, fused=True, muscles=False):
+        self.ocl_solver = owHIPSolver(cfg, position_cpp, velocity_cpp, elasticConnectionsData_cpp, membraneData_cpp,
+                                      particleMembranesList_cpp)
+        self.cfg = cfg
+        self.iterationCount = 0
+        self.fused = fused
+        self.muscles = muscles
+        self.position_cpp = np.array(position_cpp, np.float32).reshape(-1, 4)
+
+    def simulationStep(self, read_back=True):
+        s = self.ocl_solver
+        if self.fused:
+            s.step(self.iterationCount)
+        else:
+            s._runClearBuffers(); s._runHashParticles(); s._runSort(); s._runSortPostPass(); s._runIndexx()
+            s._runIndexPostPass(); s._runFindNeighbors()
+            s._run_pcisph_computeDensity(); s._run_pcisph_computeForcesAndInitPressure()
+            s._run_pcisph_computeElasticForces()
+            it = 0
+            while True:
+                s._run_pcisph_predictPositions(); s._run_pcisph_predictDensity(); s._run_pcisph_correctPressure()
+                s._run_pcisph_computePressureForceAcceleration()
+                it += 1
+                if it >= self.cfg.maxIteration:
+                    break
+            s._run_pcisph_integrate(self.iterationCount)
+            s._run_clearMembraneBuffers(); s._run_computeInteractionWithMembranes()
+            s._run_computeInteractionWithMembranes_finalize()
+        if read_back:
+            s.read_position_buffer(self.position_cpp)
+        if self.muscles:  # signals computed after step t drive step t+1 (owPhysicsFluidSimulator.cpp:134-141)
+            s.updateMuscleActivityData(muscle_signal(self.iterationCount, self.cfg.muscleCount))
+        self.iterationCount += 1
+
+    def getPosition_cpp(self): return self.position_cpp
+    def getDensity_cpp(self): return self.ocl_solver.read_density_buffer()
+    def getParticleIndex_cpp(self): return self.ocl_solver.read_particleIndex_buffer()
