@@ -1,0 +1,529 @@
+// C ABI of libsphmi.so (include/sphmi.h): solver lifetime, the 18 stage entry points that mirror
+// owOpenCLSolver::_run* (owOpenCLSolver.cpp:213-687), the fused step, read-back and reference-layout export.
+// There is no CPU path in this library: every entry point needs a HIP device and fails with SPH_ERR_HIP otherwise.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sph_common.h"
+
+static thread_local char g_err[512] = "";
+void sph_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* sph_last_error(void) { return g_err; }
+extern "C" int sph_abi_version(void) { return SPHMI_ABI_VERSION; }
+
+// stage progress bits for the order contract of simulationStep()
+enum { P_HASH = 1, P_SORT = 2, P_SORTPOST = 4, P_INDEXX = 8, P_INDEXPOST = 16, P_FIND = 32, P_DENSITY = 64, P_FORCES = 128,
+       P_PREDICTPOS = 256, P_PREDICTDENS = 512, P_PRESSUREFORCE = 1024 };
+
+#define NEED(s, bits, what)                                                              \
+  do {                                                                                   \
+    if (!(s)) { sph_set_error("null solver"); return SPH_ERR_INVALID; }                  \
+    if (((s)->progress & (bits)) != (bits)) {                                            \
+      sph_set_error("%s called before the stage(s) it depends on (simulationStep order, " \
+                    "owPhysicsFluidSimulator.cpp:88-113)", what);                        \
+      return SPH_ERR_ORDER;                                                              \
+    }                                                                                    \
+  } while (0)
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  SPH_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+  return SPH_OK;
+}
+
+static int bit_length(uint32_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+// ---------------------------------------------------------------------------------------------- timing
+struct StageTimer {
+  sph_solver* s; int stage; hipEvent_t a, b; bool on;
+  StageTimer(sph_solver* s_, int stage_) : s(s_), stage(stage_), a(nullptr), b(nullptr), on(s_->timing) {
+    if (!on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+    hipEventRecord(a, s->stream);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    hipEventRecord(b, s->stream);
+    if (s->numPending == s->capPending) {
+      s->capPending = s->capPending ? s->capPending * 2 : 256;
+      s->pending = (sph_solver::Pending*)realloc(s->pending, sizeof(sph_solver::Pending) * s->capPending);
+    }
+    s->pending[s->numPending++] = {stage, a, b};
+  }
+};
+
+static int resolve_pending(sph_solver* s) {
+  if (s->numPending == 0) return SPH_OK;
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  for (int i = 0; i < s->numPending; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->pending[i].a, s->pending[i].b) == hipSuccess) {
+      s->stageMs[s->pending[i].stage] += (double)ms;
+      s->stageLaunches[s->pending[i].stage] += 1;
+    }
+    hipEventDestroy(s->pending[i].a);
+    hipEventDestroy(s->pending[i].b);
+  }
+  s->numPending = 0;
+  return SPH_OK;
+}
+
+extern "C" int sph_set_stage_timing(sph_solver* s, int enable) {
+  if (!s) return SPH_ERR_INVALID;
+  s->timing = enable != 0;
+  return SPH_OK;
+}
+extern "C" int sph_reset_stage_times(sph_solver* s) {
+  if (!s) return SPH_ERR_INVALID;
+  int rc = resolve_pending(s);
+  memset(s->stageMs, 0, sizeof(s->stageMs));
+  memset(s->stageLaunches, 0, sizeof(s->stageLaunches));
+  return rc;
+}
+extern "C" int sph_get_stage_times(sph_solver* s, double* ms_total, int64_t* launches, int n) {
+  if (!s || n != SPH_ST_COUNT) return SPH_ERR_INVALID;
+  int rc = resolve_pending(s);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    if (ms_total) ms_total[i] = s->stageMs[i];
+    if (launches) launches[i] = s->stageLaunches[i];
+  }
+  return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- create / destroy
+static void free_all(sph_solver* s) {
+  SphDev& d = s->d;
+  void* ptrs[] = {d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
+                  d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho, d.rhoPred,
+                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, s->blockHist};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
+  free(s->pending);
+  free(s->hostScratch);
+}
+
+extern "C" int sph_destroy(sph_solver* s) {
+  if (!s) return SPH_OK;
+  hipSetDevice(s->cfg.device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (int i = 0; i < s->numPending; i++) { hipEventDestroy(s->pending[i].a); hipEventDestroy(s->pending[i].b); }
+  s->numPending = 0;
+  free_all(s);
+  delete s;
+  return SPH_OK;
+}
+
+extern "C" int sph_create(const sph_config* cfg, const float* position, const float* velocity, const float* elastic,
+                          const int32_t* membraneData, const int32_t* pml, sph_solver** out) {
+  if (!cfg || !position || !velocity || !out) { sph_set_error("sph_create: null argument"); return SPH_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->abi_version != SPHMI_ABI_VERSION) { sph_set_error("sph_config.abi_version %d != %d", cfg->abi_version, SPHMI_ABI_VERSION); return SPH_ERR_INVALID; }
+  const int N = cfg->particleCount;
+  if (N <= 0 || (long long)N * 32 >= 0x7fffffffLL * 4LL) { sph_set_error("particleCount %d out of range", N); return SPH_ERR_INVALID; }
+  if (cfg->gridCellsX <= 0 || cfg->gridCellsY <= 0 || cfg->gridCellsZ <= 0 ||
+      (long long)cfg->gridCellsX * cfg->gridCellsY * cfg->gridCellsZ != (long long)cfg->gridCellCount) {
+    sph_set_error("gridCellCount does not equal gridCellsX*gridCellsY*gridCellsZ");
+    return SPH_ERR_INVALID;
+  }
+  if (cfg->cellIdMask != 0xffffu && cfg->cellIdMask != 0xffffffffu) { sph_set_error("cellIdMask must be 0xffff (reference) or 0xffffffff (wide)"); return SPH_ERR_INVALID; }
+  if (cfg->numOfElasticP < 0 || cfg->numOfElasticP + cfg->elasticOffset > N || (cfg->numOfElasticP > 0 && !elastic)) {
+    sph_set_error("elastic configuration inconsistent");
+    return SPH_ERR_INVALID;
+  }
+  if (cfg->numOfElasticP > 0 && (cfg->muscleCount <= 0 || cfg->muscleCount > 4096)) { sph_set_error("muscleCount out of range"); return SPH_ERR_INVALID; }
+  if (cfg->maxIteration < 1) { sph_set_error("maxIteration must be >= 1"); return SPH_ERR_INVALID; }
+  if (!(cfg->h > 0.f) || !(cfg->hashGridCellSize > 0.f)) { sph_set_error("h / hashGridCellSize must be positive"); return SPH_ERR_INVALID; }
+
+  int ndev = 0;
+  SPH_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { sph_set_error("no HIP device %d (found %d): libsphmi has no CPU fallback", cfg->device, ndev); return SPH_ERR_HIP; }
+  SPH_HIP(hipSetDevice(cfg->device));
+
+  sph_solver* s = new sph_solver();
+  memset((void*)s, 0, sizeof(*s));
+  s->cfg = *cfg;
+  if (cfg->stream) { s->stream = (hipStream_t)cfg->stream; s->ownStream = false; }
+  else {
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { sph_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete s; return SPH_ERR_HIP; }
+    s->ownStream = true;
+  }
+  SphDev& d = s->d;
+  d.N = N; d.G = cfg->gridCellCount; d.gx = cfg->gridCellsX; d.gy = cfg->gridCellsY; d.gz = cfg->gridCellsZ;
+  d.cellMask = cfg->cellIdMask;
+  d.h = cfg->h; d.cellSize = cfg->hashGridCellSize; d.cellSizeInv = cfg->hashGridCellSizeInv;
+  d.simScale = cfg->simulationScale; d.simScaleInv = cfg->simulationScaleInv;
+  d.xmin = cfg->xmin; d.xmax = cfg->xmax; d.ymin = cfg->ymin; d.ymax = cfg->ymax; d.zmin = cfg->zmin; d.zmax = cfg->zmax;
+  d.r0 = cfg->r0; d.mass = cfg->mass; d.rho0 = cfg->rho0; d.dt = cfg->timeStep; d.delta = cfg->delta;
+  d.gravx = cfg->gravity_x; d.gravy = cfg->gravity_y; d.gravz = cfg->gravity_z;
+  d.surfTens = cfg->surfTensCoeff;
+  // per-step constants in the reference's exact expression types (see sph_common.h for the source lines)
+  {
+    volatile float massMu = cfg->mass * cfg->viscosity;
+    volatile float hs = cfg->h * cfg->simulationScale;
+    volatile float hs2 = hs * hs;
+    volatile float hs4 = hs2 * hs2;
+    volatile float hs6 = hs4 * hs2;
+    volatile float pts = cfg->timeStep * cfg->simulationScaleInv;
+    volatile float r0d = cfg->rho0 * cfg->delta;
+    volatile float halfHs = hs / 2;
+    d.massMu = massMu; d.hs = hs; d.hs2 = hs2; d.hs6 = hs6; d.posTimeStep = pts; d.rho0delta = r0d;
+    d.closeR = 0.5 * (double)halfHs;
+  }
+  d.massWpoly6 = ((double)cfg->mass) * cfg->Wpoly6Coefficient;
+  d.massGradW = ((double)cfg->mass) * cfg->gradWspikyCoefficient;
+  d.del2W = cfg->del2WviscosityCoefficient;
+  d.numElastic = cfg->numOfElasticP; d.elasticOffset = cfg->elasticOffset; d.muscleCount = cfg->muscleCount;
+  d.numMembranes = cfg->numOfMembranes; d.hasElastic = cfg->numOfElasticP > 0;
+
+  s->numTiles = (N + SPH_TILE - 1) / SPH_TILE;
+  s->sortBits = (cfg->cellIdMask == 0xffffu) ? 16 : bit_length((uint32_t)(d.G > 0 ? d.G - 1 : 0));
+  if (s->sortBits < 1) s->sortBits = 1;
+  s->sortBlocks = (N + (SPH_BLOCK * 16) - 1) / (SPH_BLOCK * 16);
+
+  int rc = SPH_OK;
+  const size_t n = (size_t)N, G1 = (size_t)d.G + 1, mapN = (size_t)s->numTiles * 64 * 32;
+#define A(ptr, count) if (rc == SPH_OK) rc = dev_alloc(&(ptr), (count))
+  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n);
+  A(d.keys, n); A(d.vals, n); A(d.keysAlt, n); A(d.valsAlt, n); A(d.backIndex, n);
+  A(d.cellStart, G1); A(d.cellStartRaw, G1);
+  A(d.nbrId, mapN); A(d.nbrDist, mapN);
+  A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
+  A(s->blockHist, (size_t)256 * s->sortBlocks);
+  if (d.hasElastic) {
+    A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);
+    if (membraneData && pml && cfg->numOfMembranes > 0) { A(d.membraneData, (size_t)3 * cfg->numOfMembranes); A(d.pml, (size_t)7 * d.numElastic); }
+  }
+#undef A
+  if (rc != SPH_OK) { free_all(s); delete s; return rc; }
+
+#define UP(dst, src, bytes) do { hipError_t e_ = hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, s->stream); \
+    if (e_ != hipSuccess) { sph_set_error("upload failed: %s", hipGetErrorString(e_)); free_all(s); delete s; return SPH_ERR_HIP; } } while (0)
+  UP(d.posOrig, position, sizeof(float4) * n);
+  UP(d.velOrig, velocity, sizeof(float4) * n);
+  if (d.hasElastic) {
+    UP(d.elastic, elastic, sizeof(float4) * 32 * (size_t)d.numElastic);
+    // quirk #18: the reference never uploads the signal before step 0 (zeros in practice)
+    hipMemsetAsync(d.muscle, 0, sizeof(float) * (size_t)d.muscleCount, s->stream);
+    hipMemsetAsync(d.membDelta, 0, sizeof(float4) * n, s->stream);
+    if (d.membraneData) {
+      UP(d.membraneData, membraneData, sizeof(int32_t) * 3 * (size_t)cfg->numOfMembranes);
+      UP(d.pml, pml, sizeof(int32_t) * 7 * (size_t)d.numElastic);
+    }
+  }
+#undef UP
+  // buffers the reference leaves uninitialised but that an export may read before they are written
+  hipMemsetAsync(d.predPos, 0, sizeof(float4) * n, s->stream);
+  hipMemsetAsync(d.acc, 0, sizeof(float4) * n, s->stream);
+  hipMemsetAsync(d.accP, 0, sizeof(float4) * n, s->stream);
+  hipMemsetAsync(d.rho, 0, sizeof(float) * n, s->stream);
+  hipMemsetAsync(d.rhoPred, 0, sizeof(float) * n, s->stream);
+  hipMemsetAsync(d.pressure, 0, sizeof(float) * n, s->stream);
+  hipMemsetAsync(d.nbrId, 0xff, sizeof(int32_t) * mapN, s->stream);
+  hipMemsetAsync(d.nbrDist, 0, sizeof(float) * mapN, s->stream);
+  hipMemsetAsync(d.cellStartRaw, 0, sizeof(uint32_t) * G1, s->stream);
+  hipMemsetAsync(d.cellStart, 0, sizeof(uint32_t) * G1, s->stream);
+  hipMemsetAsync(d.sortedPos, 0, sizeof(float4) * n, s->stream);
+  hipMemsetAsync(d.sortedVel, 0, sizeof(float4) * n, s->stream);
+  hipMemsetAsync(d.keys, 0, sizeof(uint32_t) * n, s->stream);
+  hipMemsetAsync(d.vals, 0, sizeof(uint32_t) * n, s->stream);
+  hipMemsetAsync(d.backIndex, 0, sizeof(uint32_t) * n, s->stream);
+  hipError_t e = hipStreamSynchronize(s->stream);  // host arrays may be freed by the caller after return
+  if (e != hipSuccess) { sph_set_error("sph_create: %s", hipGetErrorString(e)); free_all(s); delete s; return SPH_ERR_HIP; }
+  *out = s;
+  return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stages
+#define ENTER(s) do { if (!(s)) { sph_set_error("null solver"); return SPH_ERR_INVALID; } SPH_HIP(hipSetDevice((s)->cfg.device)); } while (0)
+
+extern "C" int sph_run_clear_buffers(sph_solver* s) {
+  ENTER(s);
+  StageTimer t(s, SPH_ST_FIND_NEIGHBORS);
+  return sphk_clear_neighbors(s);
+}
+extern "C" int sph_run_hash_particles(sph_solver* s) {
+  ENTER(s);
+  StageTimer t(s, SPH_ST_HASH);
+  int rc = sphk_hash(s);
+  if (rc == SPH_OK) s->progress = P_HASH;  // a new step starts here
+  return rc;
+}
+extern "C" int sph_run_sort(sph_solver* s) {
+  ENTER(s); NEED(s, P_HASH, "sph_run_sort");
+  StageTimer t(s, SPH_ST_SORT);
+  int rc = sphk_sort(s);
+  if (rc == SPH_OK) s->progress |= P_SORT;
+  return rc;
+}
+extern "C" int sph_run_sort_post_pass(sph_solver* s) {
+  ENTER(s); NEED(s, P_SORT, "sph_run_sort_post_pass");
+  StageTimer t(s, SPH_ST_SORT_POST);
+  int rc = sphk_sort_post(s);
+  if (rc == SPH_OK) s->progress |= P_SORTPOST;
+  return rc;
+}
+extern "C" int sph_run_indexx(sph_solver* s) {
+  ENTER(s); NEED(s, P_SORT, "sph_run_indexx");
+  StageTimer t(s, SPH_ST_INDEX);
+  int rc = sphk_index_raw(s);
+  if (rc == SPH_OK) s->progress |= P_INDEXX;
+  return rc;
+}
+extern "C" int sph_run_index_post_pass(sph_solver* s) {
+  ENTER(s); NEED(s, P_INDEXX, "sph_run_index_post_pass");
+  StageTimer t(s, SPH_ST_INDEX);
+  int rc = sphk_index_fixed(s);
+  if (rc == SPH_OK) s->progress |= P_INDEXPOST;
+  return rc;
+}
+extern "C" int sph_run_find_neighbors(sph_solver* s) {
+  ENTER(s); NEED(s, P_SORTPOST | P_INDEXPOST, "sph_run_find_neighbors");
+  StageTimer t(s, SPH_ST_FIND_NEIGHBORS);
+  int rc = sphk_find_neighbors(s);
+  if (rc == SPH_OK) s->progress |= P_FIND;
+  return rc;
+}
+extern "C" int sph_run_pcisph_compute_density(sph_solver* s) {
+  ENTER(s); NEED(s, P_FIND, "sph_run_pcisph_compute_density");
+  StageTimer t(s, SPH_ST_DENSITY);
+  int rc = sphk_density(s);
+  if (rc == SPH_OK) s->progress |= P_DENSITY;
+  return rc;
+}
+extern "C" int sph_run_pcisph_compute_forces_and_init_pressure(sph_solver* s) {
+  ENTER(s); NEED(s, P_DENSITY, "sph_run_pcisph_compute_forces_and_init_pressure");
+  StageTimer t(s, SPH_ST_FORCES);
+  int rc = sphk_forces(s, false);
+  if (rc == SPH_OK) s->progress |= P_FORCES;
+  return rc;
+}
+extern "C" int sph_run_pcisph_compute_elastic_forces(sph_solver* s) {
+  ENTER(s); NEED(s, P_FORCES, "sph_run_pcisph_compute_elastic_forces");
+  StageTimer t(s, SPH_ST_ELASTIC);
+  return sphk_elastic(s);
+}
+extern "C" int sph_run_pcisph_predict_positions(sph_solver* s) {
+  ENTER(s); NEED(s, P_FORCES, "sph_run_pcisph_predict_positions");
+  StageTimer t(s, SPH_ST_PRESSURE_FORCE);
+  int rc = sphk_predict_positions(s);
+  if (rc == SPH_OK) s->progress |= P_PREDICTPOS;
+  return rc;
+}
+extern "C" int sph_run_pcisph_predict_density(sph_solver* s) {
+  ENTER(s); NEED(s, P_PREDICTPOS, "sph_run_pcisph_predict_density");
+  StageTimer t(s, SPH_ST_PREDICT_DENSITY);
+  int rc = sphk_predict_density(s, false);
+  if (rc == SPH_OK) s->progress |= P_PREDICTDENS;
+  return rc;
+}
+extern "C" int sph_run_pcisph_correct_pressure(sph_solver* s) {
+  ENTER(s); NEED(s, P_PREDICTDENS, "sph_run_pcisph_correct_pressure");
+  StageTimer t(s, SPH_ST_PREDICT_DENSITY);
+  return sphk_correct_pressure(s);
+}
+extern "C" int sph_run_pcisph_compute_pressure_force_acceleration(sph_solver* s) {
+  ENTER(s); NEED(s, P_PREDICTDENS, "sph_run_pcisph_compute_pressure_force_acceleration");
+  StageTimer t(s, SPH_ST_PRESSURE_FORCE);
+  int rc = sphk_pressure_force(s, 0);
+  if (rc == SPH_OK) s->progress |= P_PRESSUREFORCE;
+  return rc;
+}
+extern "C" int sph_run_pcisph_integrate(sph_solver* s, int iterationCount) {
+  (void)iterationCount;  // only used by commented-out debug prints in the reference (sphFluid.cl:1784-1805)
+  ENTER(s); NEED(s, P_FORCES, "sph_run_pcisph_integrate");
+  StageTimer t(s, SPH_ST_INTEGRATE);
+  return sphk_integrate(s);
+}
+extern "C" int sph_run_clear_membrane_buffers(sph_solver* s) {
+  ENTER(s);
+  StageTimer t(s, SPH_ST_MEMBRANES);
+  return sphk_clear_membranes(s);
+}
+extern "C" int sph_run_compute_interaction_with_membranes(sph_solver* s) {
+  ENTER(s); NEED(s, P_FIND, "sph_run_compute_interaction_with_membranes");
+  if (!s->d.pml) return SPH_OK;  // no membrane lists were supplied
+  StageTimer t(s, SPH_ST_MEMBRANES);
+  return sphk_membranes(s);
+}
+extern "C" int sph_run_compute_interaction_with_membranes_finalize(sph_solver* s) {
+  ENTER(s);
+  StageTimer t(s, SPH_ST_MEMBRANES);
+  return sphk_membranes_finalize(s);
+}
+
+// The fused fast path. Stage sequence of simulationStep() (owPhysicsFluidSimulator.cpp:88-113) with:
+//   clearBuffers folded into findNeighbors; sortPostPass + indexx + index fix-up in one kernel;
+//   predictPositions folded into the kernel that produces the pressure acceleration it integrates
+//   (forces for iteration 0, pressure force for the later ones); correctPressure folded into predictDensity;
+//   integrate folded into the last pressure-force kernel; membrane kernels skipped when there is no elastic matter
+//   (their only effect, `position += 0`, is applied in integrate).
+extern "C" int sph_step(sph_solver* s, int iterationCount) {
+  (void)iterationCount;
+  ENTER(s);
+  int rc;
+#define RUN(stage, call) do { StageTimer t_(s, stage); rc = (call); if (rc != SPH_OK) return rc; } while (0)
+  RUN(SPH_ST_HASH, sphk_hash(s));
+  RUN(SPH_ST_SORT, sphk_sort(s));
+  RUN(SPH_ST_SORT_POST, sphk_sort_post_and_index(s));
+  RUN(SPH_ST_FIND_NEIGHBORS, sphk_find_neighbors(s));
+  RUN(SPH_ST_DENSITY, sphk_density(s));
+  RUN(SPH_ST_FORCES, sphk_forces(s, true));
+  if (s->d.hasElastic) RUN(SPH_ST_ELASTIC, sphk_elastic(s));
+  for (int iter = 0; iter < s->cfg.maxIteration; iter++) {
+    const bool last = iter == s->cfg.maxIteration - 1;
+    RUN(SPH_ST_PREDICT_DENSITY, sphk_predict_density(s, true));
+    RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force(s, last ? 2 : 1));
+  }
+  if (s->d.hasElastic) {
+    RUN(SPH_ST_MEMBRANES, sphk_clear_membranes(s));
+    if (s->d.pml) RUN(SPH_ST_MEMBRANES, sphk_membranes(s));
+    RUN(SPH_ST_MEMBRANES, sphk_membranes_finalize(s));
+  }
+#undef RUN
+  s->progress = P_HASH | P_SORT | P_SORTPOST | P_INDEXPOST | P_FIND | P_DENSITY | P_FORCES | P_PREDICTPOS | P_PREDICTDENS |
+                P_PRESSUREFORCE;
+  return SPH_OK;
+}
+
+extern "C" int sph_update_muscles(sph_solver* s, const float* signal, int n) {
+  ENTER(s);
+  if (!signal || n != s->cfg.muscleCount) { sph_set_error("sph_update_muscles: n must equal muscleCount"); return SPH_ERR_SIZE; }
+  if (!s->d.muscle) return SPH_OK;  // no elastic matter: nothing reads the signal
+  SPH_HIP(hipMemcpyAsync(s->d.muscle, signal, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+  SPH_HIP(hipStreamSynchronize(s->stream));  // blocking, like the reference's enqueueWriteBuffer(CL_TRUE)
+  return SPH_OK;
+}
+
+extern "C" int sph_synchronize(sph_solver* s) {
+  ENTER(s);
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- read-back
+static int d2h(sph_solver* s, void* dst, const void* src, size_t bytes) {
+  SPH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  return SPH_OK;
+}
+
+extern "C" int sph_read_position(sph_solver* s, float* out) {
+  ENTER(s); if (!out) return SPH_ERR_INVALID;
+  return d2h(s, out, s->d.posOrig, sizeof(float4) * (size_t)s->d.N);
+}
+extern "C" int sph_read_velocity(sph_solver* s, float* out) {
+  ENTER(s); if (!out) return SPH_ERR_INVALID;
+  return d2h(s, out, s->d.velOrig, sizeof(float4) * (size_t)s->d.N);
+}
+extern "C" int sph_read_density(sph_solver* s, float* out) {
+  ENTER(s); if (!out) return SPH_ERR_INVALID;
+  return d2h(s, out, s->d.rho, sizeof(float) * (size_t)s->d.N);
+}
+extern "C" int sph_read_particle_index(sph_solver* s, uint32_t* out) {
+  ENTER(s); if (!out) return SPH_ERR_INVALID;
+  const size_t n = (size_t)s->d.N;
+  std::vector<uint32_t> k(n), v(n);
+  int rc = d2h(s, k.data(), s->d.keys, sizeof(uint32_t) * n);
+  if (rc == SPH_OK) rc = d2h(s, v.data(), s->d.vals, sizeof(uint32_t) * n);
+  if (rc != SPH_OK) return rc;
+  for (size_t i = 0; i < n; i++) { out[2 * i] = k[i]; out[2 * i + 1] = v[i]; }
+  return SPH_OK;
+}
+
+// Export in the reference's layouts (SURVEY table 2.2). Test/inspection path: converts on the host.
+extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_t bytes, size_t* needed) {
+  ENTER(s);
+  if (!name) return SPH_ERR_INVALID;
+  const SphDev& d = s->d;
+  const size_t n = (size_t)d.N, G1 = (size_t)d.G + 1;
+  size_t need = 0;
+  enum { B_POS, B_VEL, B_SPOS, B_SVEL, B_ACC, B_NMAP, B_NIDS, B_PI, B_PIB, B_GCI, B_GCIF, B_P, B_RHO } which;
+  if (!strcmp(name, "position")) { which = B_POS; need = sizeof(float4) * 2 * n; }
+  else if (!strcmp(name, "velocity")) { which = B_VEL; need = sizeof(float4) * 2 * n; }
+  else if (!strcmp(name, "sortedPosition")) { which = B_SPOS; need = sizeof(float4) * 2 * n; }
+  else if (!strcmp(name, "sortedVelocity")) { which = B_SVEL; need = sizeof(float4) * n; }
+  else if (!strcmp(name, "acceleration")) { which = B_ACC; need = sizeof(float4) * 2 * n; }
+  else if (!strcmp(name, "neighborMap")) { which = B_NMAP; need = sizeof(float) * 2 * 32 * n; }
+  else if (!strcmp(name, "neighborIds")) { which = B_NIDS; need = sizeof(int32_t) * 32 * n; }
+  else if (!strcmp(name, "particleIndex")) { which = B_PI; need = sizeof(uint32_t) * 2 * n; }
+  else if (!strcmp(name, "particleIndexBack")) { which = B_PIB; need = sizeof(uint32_t) * n; }
+  else if (!strcmp(name, "gridCellIndex")) { which = B_GCI; need = sizeof(uint32_t) * G1; }
+  else if (!strcmp(name, "gridCellIndexFixedUp")) { which = B_GCIF; need = sizeof(uint32_t) * G1; }
+  else if (!strcmp(name, "pressure")) { which = B_P; need = sizeof(float) * n; }
+  else if (!strcmp(name, "rho")) { which = B_RHO; need = sizeof(float) * 2 * n; }
+  else { sph_set_error("unknown buffer '%s'", name); return SPH_ERR_UNKNOWN_BUFFER; }
+  if (needed) *needed = need;
+  if (!out) return SPH_OK;
+  if (bytes != need) { sph_set_error("buffer '%s' is %zu bytes, caller gave %zu", name, need, bytes); return SPH_ERR_SIZE; }
+  int rc = SPH_OK;
+  char* o = (char*)out;
+  switch (which) {
+    case B_POS:
+      rc = d2h(s, o, d.posOrig, sizeof(float4) * n);
+      if (rc == SPH_OK) { if (d.membDelta) rc = d2h(s, o + sizeof(float4) * n, d.membDelta, sizeof(float4) * n); else memset(o + sizeof(float4) * n, 0, sizeof(float4) * n); }
+      break;
+    case B_VEL:
+      rc = d2h(s, o, d.velOrig, sizeof(float4) * n);
+      memset(o + sizeof(float4) * n, 0, sizeof(float4) * n);  // the scratch half is only ever zeroed (App. B #16)
+      break;
+    case B_SPOS: {
+      std::vector<uint32_t> k(n);
+      std::vector<float4> sv(n);
+      rc = d2h(s, o, d.sortedPos, sizeof(float4) * n);
+      if (rc == SPH_OK) rc = d2h(s, o + sizeof(float4) * n, d.predPos, sizeof(float4) * n);
+      if (rc == SPH_OK) rc = d2h(s, k.data(), d.keys, sizeof(uint32_t) * n);
+      if (rc == SPH_OK) rc = d2h(s, sv.data(), d.sortedVel, sizeof(float4) * n);
+      if (rc != SPH_OK) break;
+      float4* a = (float4*)o;
+      for (size_t i = 0; i < n; i++) {
+        const int type = (int)a[i].w;
+        const float cellf = (float)(int)k[i];  // POSITION_CELL_ID = (float)cellId (sphFluid.cl:461)
+        a[i].w = cellf;
+        // .w of the predicted half is dead data in the reference: cell id for boundary particles, cell id + posTimeStep *
+        // (v.w + dt*a_p.w) otherwise, with a_p.w == 0
+        a[n + i].w = (type == SPH_BOUNDARY_PARTICLE) ? cellf : cellf + d.posTimeStep * (sv[i].w + d.dt * 0.f);
+      }
+    } break;
+    case B_SVEL: rc = d2h(s, o, d.sortedVel, sizeof(float4) * n); break;
+    case B_ACC:
+      rc = d2h(s, o, d.acc, sizeof(float4) * n);
+      if (rc == SPH_OK) rc = d2h(s, o + sizeof(float4) * n, d.accP, sizeof(float4) * n);
+      break;
+    case B_NMAP:
+    case B_NIDS: {
+      const size_t mapN = (size_t)s->numTiles * 64 * 32;
+      std::vector<int32_t> ids(mapN);
+      std::vector<float> dist(mapN);
+      rc = d2h(s, ids.data(), d.nbrId, sizeof(int32_t) * mapN);
+      if (rc == SPH_OK) rc = d2h(s, dist.data(), d.nbrDist, sizeof(float) * mapN);
+      if (rc != SPH_OK) break;
+      for (size_t id = 0; id < n; id++)
+        for (int k = 0; k < 32; k++) {
+          const size_t src = nbr_index((int)id, k);
+          if (which == B_NIDS) ((int32_t*)o)[id * 32 + k] = ids[src];
+          else { ((float*)o)[(id * 32 + k) * 2] = (float)ids[src]; ((float*)o)[(id * 32 + k) * 2 + 1] = dist[src]; }
+        }
+    } break;
+    case B_PI: rc = sph_read_particle_index(s, (uint32_t*)o); break;
+    case B_PIB: rc = d2h(s, o, d.backIndex, sizeof(uint32_t) * n); break;
+    case B_GCI: rc = d2h(s, o, d.cellStartRaw, sizeof(uint32_t) * G1); break;
+    case B_GCIF: rc = d2h(s, o, d.cellStart, sizeof(uint32_t) * G1); break;
+    case B_P: rc = d2h(s, o, d.pressure, sizeof(float) * n); break;
+    case B_RHO:
+      rc = d2h(s, o, d.rho, sizeof(float) * n);
+      if (rc == SPH_OK) rc = d2h(s, o + sizeof(float) * n, d.rhoPred, sizeof(float) * n);
+      break;
+  }
+  return rc;
+}

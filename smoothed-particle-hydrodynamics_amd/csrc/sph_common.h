@@ -1,0 +1,121 @@
+// Internal declarations of libsphmi.so (gfx950 only). Data layout in HBM — see DESIGN.md §3.
+//
+//   orig order (API state)      posOrig  float4[N] (x,y,z,type)        velOrig float4[N] (vx,vy,vz,w)
+//   sorted order (per step)     sortedPos float4[N] (x,y,z,type)       sortedVel float4[N]     predPos float4[N]
+//                               keys u32[N] (cell)  vals u32[N] (orig id)  backIndex u32[N] (orig -> sorted)
+//                               rho / rhoPred / pressure f32[N]        acc / accP float4[N]
+//   neighbour map, tiled        nbrId i32, nbrDist f32: [tile = id/64][group = slot/4][lane = id%64][slot%4]
+//                               -> one wave reads 4 slots of its 64 particles as ONE contiguous 1-KiB transaction
+//   grid                        cellStart u32[G+1]  (== gridCellIndexFixedUp: #particles with cell < c)
+//
+// float4 is kept for everything that other particles gather (one 16-B transaction per neighbour instead of
+// three 4-B ones); pure per-particle streams (map, rho, pressure) are SoA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "sphmi.h"
+
+#define SPH_BLOCK 256
+#define SPH_TILE 64
+#define SPH_MAXN 32
+#define SPH_RSEG 30  // radius_segments, sphFluid.cl:116
+
+struct SphDev {  // what the kernels see; passed by value
+  int N, G;
+  int gx, gy, gz;
+  uint32_t cellMask;
+  float h, cellSize, cellSizeInv, simScale, simScaleInv;
+  float xmin, xmax, ymin, ymax, zmin, zmax;
+  float r0, mass, rho0, dt, delta;
+  float gravx, gravy, gravz;
+  float surfTens;      // sphFluid.cl:662
+  float massMu;        // (float)(mass*mu), sphFluid.cl:688
+  float hs, hs2, hs6;  // hScaled, hScaled^2, hScaled^6 (float products as in sphFluid.cl:495-497)
+  float posTimeStep;   // timeStep * simulationScaleInv (sphFluid.cl:928)
+  float rho0delta;     // rho0*delta (sphFluid.cl:1168)
+  double massWpoly6;   // ((double)mass)*Wpoly6Coefficient (sphFluid.cl:516)
+  double massGradW;    // ((double)mass)*gradWspikyCoefficient (sphFluid.cl:1194)
+  double del2W;        // del2WviscosityCoefficient
+  double closeR;       // 0.5*(hScaled/2) as the double the comparison at sphFluid.cl:1166 uses
+  int numElastic, elasticOffset, muscleCount, numMembranes;
+  int hasElastic;      // 0: membrane kernels are no-ops and are folded into integrate
+  // buffers
+  float4 *posOrig, *velOrig, *membDelta;
+  float4 *sortedPos, *sortedVel, *predPos, *acc, *accP;
+  uint32_t *keys, *vals, *keysAlt, *valsAlt, *backIndex;
+  uint32_t *cellStart, *cellStartRaw;
+  int32_t* nbrId;
+  float* nbrDist;
+  float *rho, *rhoPred, *pressure;
+  float4* elastic;
+  int32_t *membraneData, *pml;
+  float* muscle;
+};
+
+struct sph_solver {
+  sph_config cfg;
+  SphDev d;
+  hipStream_t stream;
+  bool ownStream;
+  int sortBits;              // significant bits of the sort key
+  int numTiles;              // ceil(N/64)
+  // radix-sort workspace
+  uint32_t* blockHist;       // [256][sortBlocks]
+  int sortBlocks;
+  // stage progress for SPH_ERR_ORDER checks
+  int progress;
+  // stage timing
+  bool timing;
+  hipEvent_t evStart[SPH_ST_COUNT], evStop[SPH_ST_COUNT];
+  struct Pending { int stage; hipEvent_t a, b; };
+  Pending* pending; int numPending, capPending;
+  double stageMs[SPH_ST_COUNT];
+  int64_t stageLaunches[SPH_ST_COUNT];
+  // host staging for exports
+  void* hostScratch; size_t hostScratchBytes;
+};
+
+void sph_set_error(const char* fmt, ...);
+
+#define SPH_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (call);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      sph_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return SPH_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+static inline int sph_blocks(int n, int per = SPH_BLOCK) { return (n + per - 1) / per; }
+
+// index of (sorted particle id, slot) in the tiled neighbour map
+__host__ __device__ static inline size_t nbr_index(int id, int slot) {
+  return ((((size_t)(id >> 6) * 8 + (size_t)(slot >> 2)) * 64 + (size_t)(id & 63)) << 2) + (size_t)(slot & 3);
+}
+
+// ---- launchers (each enqueues on s->stream and returns SPH_OK / SPH_ERR_HIP) ----
+// sph_sort.hip
+int sphk_hash(sph_solver* s);
+int sphk_sort(sph_solver* s);
+int sphk_sort_post(sph_solver* s);        // gather + backIndex (K3)
+int sphk_index_raw(sph_solver* s);        // K4 table with -1 for empty cells
+int sphk_index_fixed(sph_solver* s);      // H2 table (cellStart)
+int sphk_sort_post_and_index(sph_solver* s);  // fused K3 + K4 + H2
+// sph_neighbors.hip
+int sphk_clear_neighbors(sph_solver* s);
+int sphk_find_neighbors(sph_solver* s);
+// sph_pcisph.hip
+int sphk_density(sph_solver* s);
+int sphk_forces(sph_solver* s, bool fusePredict);
+int sphk_predict_positions(sph_solver* s);
+int sphk_predict_density(sph_solver* s, bool fuseCorrect);
+int sphk_correct_pressure(sph_solver* s);
+int sphk_pressure_force(sph_solver* s, int fuse);  // 0 none, 1 + predictPositions, 2 + integrate
+int sphk_integrate(sph_solver* s);
+// sph_elastic.hip
+int sphk_elastic(sph_solver* s);
+int sphk_clear_membranes(sph_solver* s);
+int sphk_membranes(sph_solver* s);
+int sphk_membranes_finalize(sph_solver* s);

@@ -1,0 +1,343 @@
+// PCISPH kernels K6, K7, K9-K13 (sphFluid.cl:472-708, 824-1212, 1684-1808) for gfx950.
+//
+// One lane per sorted particle (the reference's `id = particleIndexBack[get_global_id]` is a pure thread permutation and
+// is dropped — SURVEY App. B #11). Every kernel streams its own 32 neighbour slots as eight coalesced 16-byte loads
+// per lane from the tiled map (1 KiB per wave-instruction) and gathers neighbour state as single float4 transactions.
+// Arithmetic keeps the reference's operand types and evaluation order: no FMA contraction, IEEE division/sqrt,
+// f32 denormals kept, f64 where sphFluid.cl uses double.
+#include "sph_common.h"
+
+#define TYPE_OF(p4) ((int)(p4).w)
+
+// the 8 x (int4 ids, float4 dists) of particle `id`
+struct NbrTile {
+  const int4* ids;
+  const float4* dist;
+  __device__ __forceinline__ NbrTile(const SphDev& d, int id) {
+    const size_t base = ((size_t)(id >> 6) * 8) * 64 + (size_t)(id & 63);
+    ids = reinterpret_cast<const int4*>(d.nbrId) + base;
+    dist = reinterpret_cast<const float4*>(d.nbrDist) + base;
+  }
+  __device__ __forceinline__ int4 id4(int g) const { return ids[(size_t)g * 64]; }
+  __device__ __forceinline__ float4 dist4(int g) const { return dist[(size_t)g * 64]; }
+};
+
+// XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs; remap so that each
+// XCD works on one contiguous eighth of the sorted particle range and its L2 holds only that slab's neighbourhood.
+__device__ __forceinline__ int xcd_block(int nblocks) {
+  const int b = blockIdx.x;
+  const int per = nblocks >> 3;  // blocks per XCD in the evenly divisible part
+  const int even = per << 3;
+  if (b >= even) return b;       // tail blocks keep their index
+  return (b & 7) * per + (b >> 3);
+}
+
+// ------------------------------------------------------------------ K6 pcisph_computeDensity (sphFluid.cl:472-518)
+// The HBM-roofline-graded pass: reads 32 x 4 B of distances, writes 4 B. The empty-slot test uses the distance
+// sentinel (-1), which is set iff the id is -1 (both are written together), so the id half of the map is not read.
+__global__ __launch_bounds__(SPH_BLOCK) void k_density(SphDev d, int nblocks) {
+  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const NbrTile t(d, id);
+  float4 r[8];
+#pragma unroll
+  for (int g = 0; g < 8; g++) r[g] = t.dist4(g);  // all 8 loads in flight before the first use
+  double density = 0.0;
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const float rr[4] = {r[g].x, r[g].y, r[g].z, r[g].w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (rr[k] != -1.f) {
+        const float r2 = rr[k] * rr[k];
+        const float a = d.hs2 - r2;
+        density += (double)(a * a * a);  // no r < hScaled test here
+      }
+    }
+  }
+  if (density < (double)d.hs6) density = (double)d.hs6;
+  density *= d.massWpoly6;
+  d.rho[id] = (float)density;
+}
+
+int sphk_density(sph_solver* s) {
+  const int nb = sph_blocks(s->d.N);
+  hipLaunchKernelGGL(k_density, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ K9 pcisph_predictPositions (sphFluid.cl:889-979)
+__device__ __forceinline__ float4 predict_position(const SphDev& d, const float4 x, const float4 v, const float4 ap) {
+  if (TYPE_OF(x) == SPH_BOUNDARY_PARTICLE) return x;
+  // v* = v + dt*a_p (pressure acceleration only, :924); x* = x + (dt/simScale)*v*
+  float4 o;
+  o.x = x.x + d.posTimeStep * (v.x + d.dt * ap.x);
+  o.y = x.y + d.posTimeStep * (v.y + d.dt * ap.y);
+  o.z = x.z + d.posTimeStep * (v.z + d.dt * ap.z);
+  o.w = x.w;  // dead in the reference (holds cell id + ...); we keep the type
+  return o;
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_predict_positions(SphDev d) {
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  d.predPos[id] = predict_position(d, d.sortedPos[id], d.sortedVel[id], d.accP[id]);
+}
+
+int sphk_predict_positions(sph_solver* s) {
+  hipLaunchKernelGGL(k_predict_positions, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ K7 pcisph_computeForcesAndInitPressure (sphFluid.cl:589-708)
+template <bool FUSE_PREDICT>
+__global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
+  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 xi = d.sortedPos[id];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
+    d.acc[id] = zero; d.accP[id] = zero; d.pressure[id] = 0.f;
+    if (FUSE_PREDICT) d.predPos[id] = xi;
+    return;
+  }
+  const float4 vi = d.sortedVel[id];
+  const NbrTile t(d, id);
+  float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll 2
+  for (int g = 0; g < 8; g++) {
+    const int4 j4 = t.id4(g);
+    const float4 r4 = t.dist4(g);
+    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+    const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int jd = jj[k];
+      if (jd != -1 && rr[k] < d.hs) {
+        const float4 vj = d.sortedVel[jd];   // for a boundary neighbour this is its wall normal (sphFluid.cl:653)
+        const float4 xj = d.sortedPos[jd];
+        const float rj = d.rho[jd];
+        const float w = d.hs - rr[k];
+        sx += (vj.x - vi.x) * w / rj;
+        sy += (vj.y - vi.y) * w / rj;
+        sz += (vj.z - vi.z) * w / rj;
+        tx += d.surfTens * (xi.x - xj.x);
+        ty += d.surfTens * (xi.y - xj.y);
+        tz += d.surfTens * (xi.z - xj.z);
+      }
+    }
+  }
+  const float scale = d.massMu * (float)(d.del2W / (double)d.rho[id]);
+  float4 a;
+  a.x = sx * scale + d.gravx + tx;
+  a.y = sy * scale + d.gravy + ty;
+  a.z = sz * scale + d.gravz + tz;
+  a.w = 0.f;  // acceleration.w is never read (integrate zeroes it, sphFluid.cl:1721)
+  d.acc[id] = a;
+  d.accP[id] = zero;
+  d.pressure[id] = 0.f;
+  if (FUSE_PREDICT) d.predPos[id] = predict_position(d, xi, vi, zero);
+}
+
+int sphk_forces(sph_solver* s, bool fusePredict) {
+  const int nb = sph_blocks(s->d.N);
+  if (fusePredict) hipLaunchKernelGGL((k_forces<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  else hipLaunchKernelGGL((k_forces<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ K10 pcisph_predictDensity (+ K11 correctPressure)
+// (sphFluid.cl:982-1059, 1062-1098)
+__device__ __forceinline__ float corrected_pressure(const SphDev& d, float p, float rhoPred) {
+  const float rho_err = rhoPred - d.rho0;
+  float p_corr = rho_err * d.delta;
+  if (p_corr < 0.f) p_corr = 0.f;
+  return p + p_corr;
+}
+
+template <bool FUSE_CORRECT>
+__global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nblocks) {
+  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 xi = d.predPos[id];
+  const NbrTile t(d, id);
+  double density = 0.0;
+#pragma unroll 2
+  for (int g = 0; g < 8; g++) {
+    const int4 j4 = t.id4(g);
+    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int jd = jj[k];
+      if (jd != -1) {
+        const float4 xj = d.predPos[jd];
+        const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
+        const float r2 = (rx * rx + ry * ry + rz * rz) * d.simScale * d.simScale;
+        if (r2 < d.hs2) {
+          const float a = d.hs2 - r2;
+          density += (double)(a * a * a);
+        }
+      }
+    }
+  }
+  if (density < (double)d.hs6) density = (double)d.hs6;
+  density *= d.massWpoly6;
+  const float rp = (float)density;
+  d.rhoPred[id] = rp;
+  if (FUSE_CORRECT) d.pressure[id] = corrected_pressure(d, d.pressure[id], rp);
+}
+
+int sphk_predict_density(sph_solver* s, bool fuseCorrect) {
+  const int nb = sph_blocks(s->d.N);
+  if (fuseCorrect) hipLaunchKernelGGL((k_predict_density<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  else hipLaunchKernelGGL((k_predict_density<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_correct_pressure(SphDev d) {
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  d.pressure[id] = corrected_pressure(d, d.pressure[id], d.rhoPred[id]);
+}
+
+int sphk_correct_pressure(sph_solver* s) {
+  hipLaunchKernelGGL(k_correct_pressure, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ K13 pcisph_integrate (sphFluid.cl:1684-1808)
+// + computeInteractionWithBoundaryParticles (sphFluid.cl:824-887), tangVel = true.
+// Boundary neighbours are read from the sorted arrays: boundary particles never move, so sortedPos/sortedVel hold the
+// same bits as position[]/velocity[] of the reference and the particleIndex indirection is unnecessary.
+__device__ __forceinline__ void integrate_particle(const SphDev& d, int id, const float4 x, const float4 v, const float4 a0,
+                                                   const float4 a1) {
+  const float ax = a0.x + a1.x, ay = a0.y + a1.y, az = a0.z + a1.z;  // acceleration_.w = 0
+  float nvx = v.x + d.dt * ax, nvy = v.y + d.dt * ay, nvz = v.z + d.dt * az, nvw = v.w + d.dt * 0.f;
+  float nx = x.x + d.posTimeStep * nvx, ny = x.y + d.posTimeStep * nvy, nz = x.z + d.posTimeStep * nvz;
+  if (nx < d.xmin) nx = d.xmin;
+  if (ny < d.ymin) ny = d.ymin;
+  if (nz < d.zmin) nz = d.zmin;
+  if (nx > d.xmax - 0.000001f) nx = d.xmax - 0.000001f;
+  if (ny > d.ymax - 0.000001f) ny = d.ymax - 0.000001f;
+  if (nz > d.zmax - 0.000001f) nz = d.zmax - 0.000001f;
+  nvx = (v.x + nvx) * 0.5f; nvy = (v.y + nvy) * 0.5f; nvz = (v.z + nvz) * 0.5f; nvw = (v.w + nvw) * 0.5f;
+
+  const NbrTile t(d, id);
+  float ncx = 0.f, ncy = 0.f, ncz = 0.f, ncw = 0.f, wsum = 0.f, wsum2 = 0.f;
+#pragma unroll 2
+  for (int g = 0; g < 8; g++) {
+    const int4 j4 = t.id4(g);
+    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int jb = jj[k];
+      if (jb == -1) continue;
+      const float4 pb = d.sortedPos[jb];
+      if (TYPE_OF(pb) != SPH_BOUNDARY_PARTICLE) continue;
+      float dist = (nx - pb.x) * (nx - pb.x);
+      dist += (ny - pb.y) * (ny - pb.y);
+      dist += (nz - pb.z) * (nz - pb.z);
+      dist = sqrtf(dist);
+      const float w = fmaxf(0.f, (d.r0 - dist) / d.r0);  // Ihmsen 2010 (10)
+      const float4 nb = d.sortedVel[jb];                  // wall normal, stored in the velocity slot
+      ncx += nb.x * w; ncy += nb.y * w; ncz += nb.z * w; ncw += nb.w * w;
+      wsum += w;
+      wsum2 += w * (d.r0 - dist);
+    }
+  }
+  float len = ((ncx * ncx + ncy * ncy) + ncz * ncz) + ncw * ncw;  // dot(float4,float4) incl. the .w lane
+  if (len != 0.f) {
+    len = sqrtf(len);
+    nx += ((ncx / len) * wsum2) / wsum;
+    ny += ((ncy / len) * wsum2) / wsum;
+    nz += ((ncz / len) * wsum2) / wsum;
+    const float vn = ncx * nvx + ncy * nvy + ncz * nvz;  // un-normalised n_c_i (sphFluid.cl:878)
+    if (vn < 0.f) {
+      nvx -= ncx * vn; nvy -= ncy * vn; nvz -= ncz * vn;
+      nvx *= 0.99f; nvy *= 0.99f; nvz *= 0.99f; nvw *= 0.99f;
+    }
+  }
+  if (!d.hasElastic) {
+    // no elastic matter: the three membrane kernels reduce to `position += 0` for non-boundary particles
+    // (sphFluid.cl:1673 with an all-zero scratch half); fold that add in so the bits match (-0 + 0 = +0).
+    nx += 0.f; ny += 0.f; nz += 0.f;
+  }
+  const uint32_t src = d.vals[id];
+  d.velOrig[src] = make_float4(nvx, nvy, nvz, nvw);
+  d.posOrig[src] = make_float4(nx, ny, nz, x.w);  // (x,y,z,type) in one store
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_integrate(SphDev d, int nblocks) {
+  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 x = d.sortedPos[id];
+  if (TYPE_OF(x) == SPH_BOUNDARY_PARTICLE) return;
+  integrate_particle(d, id, x, d.sortedVel[id], d.acc[id], d.accP[id]);
+}
+
+int sphk_integrate(sph_solver* s) {
+  const int nb = sph_blocks(s->d.N);
+  hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ K12 pcisph_computePressureForceAcceleration
+// (sphFluid.cl:1101-1212). FUSE: 0 = alone, 1 = + next iteration's predictPositions, 2 = + integrate (last iteration).
+template <int FUSE>
+__global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblocks) {
+  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 xi = d.sortedPos[id];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
+    d.accP[id] = zero;
+    if (FUSE == 1) d.predPos[id] = xi;
+    return;
+  }
+  const float pi_ = d.pressure[id];
+  const NbrTile t(d, id);
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  const float hq = d.hs * 0.25f;
+#pragma unroll 2
+  for (int g = 0; g < 8; g++) {
+    const int4 j4 = t.id4(g);
+    const float4 r4 = t.dist4(g);
+    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+    const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int jd = jj[k];
+      const float r = rr[k];
+      if (jd != -1 && r < d.hs) {
+        const float4 xj = d.sortedPos[jd];
+        const float rpj = d.rhoPred[jd];
+        float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + d.pressure[jd]) / rpj;
+        const float vx = (xi.x - xj.x) * d.simScale, vy = (xi.y - xj.y) * d.simScale, vz = (xi.z - xj.z) * d.simScale;
+        if ((double)r < d.closeR) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj;
+        rx += value * vx / r;
+        ry += value * vy / r;
+        rz += value * vz / r;
+      }
+    }
+  }
+  const float scale = (float)(d.massGradW / (double)d.rhoPred[id]);
+  const float4 ap = make_float4(rx * scale, ry * scale, rz * scale, 0.f);
+  d.accP[id] = ap;
+  if (FUSE == 1) d.predPos[id] = predict_position(d, xi, d.sortedVel[id], ap);
+  if (FUSE == 2) integrate_particle(d, id, xi, d.sortedVel[id], d.acc[id], ap);
+}
+
+int sphk_pressure_force(sph_solver* s, int fuse) {
+  const int nb = sph_blocks(s->d.N);
+  if (fuse == 0) hipLaunchKernelGGL((k_pressure_force<0>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  else if (fuse == 1) hipLaunchKernelGGL((k_pressure_force<1>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  else hipLaunchKernelGGL((k_pressure_force<2>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}

@@ -1,0 +1,196 @@
+// Cell binning on the device: hash (K2), stable LSD radix sort by cell id (replaces the reference's host qsort,
+// owOpenCLSolver.cpp:255-261), gather into sorted order (K3) and the cell-start table (K4 + the host fix-up loop,
+// owOpenCLSolver.cpp:305-319). No device->host round trip, unlike the reference.
+#include "sph_common.h"
+
+// ------------------------------------------------------------------ K2 hashParticles (sphFluid.cl:187-201,332-383)
+__global__ __launch_bounds__(SPH_BLOCK) void k_hash(SphDev d) {
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 p = d.posOrig[id];
+  // cellFactors ignores xmin/ymin/zmin (sphFluid.cl:197-199)
+  const int cx = (int)(p.x * d.cellSizeInv), cy = (int)(p.y * d.cellSizeInv), cz = (int)(p.z * d.cellSizeInv);
+  const int cell = cx + cy * d.gx + cz * d.gx * d.gy;
+  d.keys[id] = (uint32_t)cell & d.cellMask;  // `& 0xffff` at sphFluid.cl:377 in reference mode
+  d.vals[id] = (uint32_t)id;
+}
+
+int sphk_hash(sph_solver* s) {
+  hipLaunchKernelGGL(k_hash, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ stable LSD radix sort, 8 bits per pass
+// Tile = 256 threads x 16 keys. Wave w of a block owns the contiguous 1024 keys [w*1024, (w+1)*1024) of the tile and
+// walks them in 16 rounds of 64, so "earlier in memory" == (block, wave, round, lane) order and ranks stay stable:
+// myCompare orders by cell only and glibc's qsort keeps ties in input (= ascending orig id) order.
+#define RS_ITEMS 16
+#define RS_TILE (SPH_BLOCK * RS_ITEMS)
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_radix_hist(const uint32_t* __restrict__ keys, int N, int shift,
+                                                           uint32_t* __restrict__ blockHist, int numBlocks) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int i = base + r * SPH_BLOCK + threadIdx.x;
+    if (i < N) atomicAdd(&hist[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  blockHist[(size_t)threadIdx.x * numBlocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of blockHist[256*numBlocks] (digit-major) by a single 1024-thread block
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ blockHist, int total) {
+  __shared__ uint32_t part[1024];
+  const int per = (total + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(lo + per, total);
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; i++) sum += blockHist[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (int i = lo; i < hi; i++) { uint32_t v = blockHist[i]; blockHist[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __restrict__ keysIn,
+                                                              const uint32_t* __restrict__ valsIn,
+                                                              uint32_t* __restrict__ keysOut,
+                                                              uint32_t* __restrict__ valsOut, int N, int shift,
+                                                              const uint32_t* __restrict__ blockHist, int numBlocks) {
+  __shared__ volatile uint32_t waveCount[4][256];  // running count of digit d inside wave w's range
+  __shared__ uint32_t digitBase[4][256];  // global output index of the first key with digit d of wave w
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 4 * 256; i += SPH_BLOCK) waveCount[i >> 8][i & 255] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * RS_TILE + wave * (64 * RS_ITEMS);
+  const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < N;
+    key[r] = valid ? keysIn[i] : 0u;
+    val[r] = valid ? valsIn[i] : 0u;
+    const uint32_t dgt = (key[r] >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (dgt >> b) & 1u;
+      const unsigned long long m = __ballot(valid && bit);
+      peers &= bit ? m : ~m;
+    }
+    // all peers read the running count, then the lowest peer bumps it (LDS ops of one wave retire in order)
+    const uint32_t before = valid ? waveCount[wave][dgt] : 0u;
+    rank[r] = before + (uint32_t)__popcll(peers & ltMask);
+    if (valid && (peers & ltMask) == 0ull) waveCount[wave][dgt] = before + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    const int dgt = threadIdx.x;  // one thread per digit
+    uint32_t run = blockHist[(size_t)dgt * numBlocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { digitBase[w][dgt] = run; run += waveCount[w][dgt]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int i = base + r * 64 + lane;
+    if (i < N) {
+      const uint32_t dst = digitBase[wave][(key[r] >> shift) & 255u] + rank[r];
+      keysOut[dst] = key[r];
+      valsOut[dst] = val[r];
+    }
+  }
+}
+
+int sphk_sort(sph_solver* s) {
+  SphDev& d = s->d;
+  const int nb = s->sortBlocks;
+  for (int shift = 0; shift < s->sortBits; shift += 8) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.N, shift, s->blockHist, nb);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s->stream, s->blockHist, 256 * nb);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.vals, d.keysAlt, d.valsAlt,
+                       d.N, shift, s->blockHist, nb);
+    uint32_t* t = d.keys; d.keys = d.keysAlt; d.keysAlt = t;
+    t = d.vals; d.vals = d.valsAlt; d.valsAlt = t;
+  }
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// ------------------------------------------------------------------ K3 sortPostPass (sphFluid.cl:441-466)
+// + K4 indexx (sphFluid.cl:385-439) + host fix-up (owOpenCLSolver.cpp:305-319).
+// cellStart[c] = number of particles whose cell id is < c: for a non-empty cell its first sorted index, for an empty
+// one the start of the next non-empty cell, [0] = 0, [G] = N — exactly the fixed-up table. Every thread whose key
+// differs from its predecessor's fills the run of cells in between, so no binary search and no host pass are needed.
+template <bool GATHER, bool INDEX>
+__global__ __launch_bounds__(SPH_BLOCK) void k_sort_post(SphDev d) {
+  const int i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (i >= d.N) return;
+  const uint32_t key = d.keys[i];
+  if (GATHER) {
+    const uint32_t src = d.vals[i];
+    d.sortedPos[i] = d.posOrig[src];  // .w stays the particle type; the cell id lives in keys[]
+    d.sortedVel[i] = d.velOrig[src];
+    d.backIndex[src] = (uint32_t)i;
+  }
+  if (INDEX) {
+    const uint32_t G = (uint32_t)d.G;
+    if (i == 0) {
+      for (uint32_t c = 0; c <= min(key, G); c++) d.cellStart[c] = 0u;
+    } else {
+      const uint32_t prev = d.keys[i - 1];
+      if (prev != key)
+        for (uint32_t c = prev + 1; c <= min(key, G); c++) d.cellStart[c] = (uint32_t)i;
+    }
+    if (i == d.N - 1)
+      for (uint32_t c = key + 1; c <= G; c++) d.cellStart[c] = (uint32_t)d.N;
+  }
+}
+
+int sphk_sort_post(sph_solver* s) {
+  hipLaunchKernelGGL((k_sort_post<true, false>), dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+int sphk_index_fixed(sph_solver* s) {
+  hipLaunchKernelGGL((k_sort_post<false, true>), dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+int sphk_sort_post_and_index(sph_solver* s) {
+  hipLaunchKernelGGL((k_sort_post<true, true>), dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+// K4 alone, for stage-by-stage parity: first sorted index of each non-empty cell, 0xffffffff (NO_PARTICLE_ID) for empty
+// cells, [0] = 0 and [G] = N as sphFluid.cl:398-406 sets them.
+__global__ __launch_bounds__(SPH_BLOCK) void k_index_raw(SphDev d) {
+  const int i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (i >= d.N) return;
+  const uint32_t key = d.keys[i];
+  if (key < (uint32_t)d.G && key > 0u && (i == 0 || d.keys[i - 1] != key)) d.cellStartRaw[key] = (uint32_t)i;
+}
+__global__ void k_index_raw_ends(SphDev d) {
+  d.cellStartRaw[0] = 0u;
+  d.cellStartRaw[d.G] = (uint32_t)d.N;
+}
+
+int sphk_index_raw(sph_solver* s) {
+  SPH_HIP(hipMemsetAsync(s->d.cellStartRaw, 0xff, sizeof(uint32_t) * ((size_t)s->d.G + 1), s->stream));
+  hipLaunchKernelGGL(k_index_raw, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  hipLaunchKernelGGL(k_index_raw_ends, dim3(1), dim3(1), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}

@@ -1,0 +1,212 @@
+"""Scene builders shared by the tests, the golden generator and bench.py (inputs only — no solver code)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import sphmi  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def liquid_box(box_in_h, lattice, spacing_in_r0=0.93, jitter_in_r0=0.0, mask=0xffff, origin_in_r0=(3.0, 3.0, 3.0),
+               seed=20261004):
+    """Pure-liquid synthetic box: liquid lattice first, then the reference boundary shell."""
+    cfg = sphmi.default_config()
+    sphmi.set_box(cfg, box_in_h[0], box_in_h[1], box_in_h[2], mask)
+    r0 = np.float32(cfg.r0)
+    pos, vel, counts = sphmi.generate_box(cfg, lattice[0], lattice[1], lattice[2],
+                                          spacing=np.float32(spacing_in_r0) * r0,
+                                          origin=tuple(np.float32(o) * r0 for o in origin_in_r0),
+                                          jitter=float(np.float32(jitter_in_r0) * r0), seed=seed)
+    return dict(cfg=cfg, position=pos, velocity=vel, elastic=None, membranes=None, particle_membranes=None, **counts)
+
+
+def elastic_sheet_box(box_in_h=(8.0, 8.0, 8.0), lattice=(10, 8, 10), sheet=(8, 8), muscles=True):
+    """Small scene with every particle kind: an elastic sheet (springs, one muscle, triangular membranes) lying in a
+    liquid lattice inside the boundary shell. Order as the reference generator: elastic, liquid, boundary; the
+    connection / membrane encodings follow owHelper.cpp:990-1000,1240-1420 (j+0.1, r_ij*simScale*0.95, muscle.colour)."""
+    base = liquid_box(box_in_h, lattice, spacing_in_r0=0.93)
+    cfg = base["cfg"]
+    r0 = np.float32(cfg.r0)
+    sx, sz = sheet
+    # sheet in the x-z plane at a height that cuts through the liquid lattice, spacing r0, elastic type 2.1
+    y = np.float32(3.0) * r0 + np.float32(3.45) * np.float32(0.93) * r0
+    ex = (np.float32(3.3) * r0 + np.arange(sx, dtype=np.float32) * r0)
+    ez = (np.float32(3.3) * r0 + np.arange(sz, dtype=np.float32) * r0)
+    epos = np.zeros((sx * sz, 4), np.float32)
+    for iz in range(sz):
+        for ix in range(sx):
+            epos[iz * sx + ix] = (ex[ix], y, ez[iz], np.float32(2.1))
+    E = epos.shape[0]
+    # remove liquid particles closer than 0.6 r0 to a sheet particle (avoid start-up overlaps)
+    nl = base["numOfLiquidP"]
+    liq = base["position"][:nl]
+    d2 = ((liq[:, None, :3] - epos[None, :, :3]) ** 2).sum(-1)
+    keep = d2.min(1) > (0.6 * float(r0)) ** 2
+    liq = liq[keep]
+    bnd_p, bnd_v = base["position"][nl:], base["velocity"][nl:]
+    pos = np.concatenate([epos, liq, bnd_p]).astype(np.float32)
+    vel = np.concatenate([np.zeros_like(epos), np.zeros_like(liq), bnd_v]).astype(np.float32)
+    # springs: neighbours within r0*sqrt(2.7) (owHelper.cpp:989); row-major, -1 terminated
+    elastic = np.zeros((E * 32, 4), np.float32)
+    elastic[:, 0] = -1.0
+    sim = np.float32(cfg.simulationScale)
+    for i in range(E):
+        ecc = 0
+        for j in range(E):
+            if i == j:
+                continue
+            dx = epos[i, :3] - epos[j, :3]
+            r = np.sqrt(np.float32((dx * dx).sum()))
+            if r <= r0 * np.sqrt(np.float32(2.7)) and ecc < 32:
+                muscle = 0.0
+                if muscles and (i // sx == j // sx) and (i // sx) == sz // 2:  # one row of x-springs is muscle #1
+                    muscle = 1.2
+                elastic[i * 32 + ecc] = (np.float32(j) + np.float32(0.1), np.float32(r * sim * np.float32(0.95)), muscle, 0)
+                ecc += 1
+    # membranes: two triangles per grid square; per-particle membrane lists (<= 7, -1 padded)
+    tris = []
+    for iz in range(sz - 1):
+        for ix in range(sx - 1):
+            a, b, c, d = iz * sx + ix, iz * sx + ix + 1, (iz + 1) * sx + ix, (iz + 1) * sx + ix + 1
+            tris.append((a, b, c))
+            tris.append((b, d, c))
+    membranes = np.array(tris, np.int32)
+    pml = -np.ones((E, 7), np.int32)
+    fill = np.zeros(E, np.int32)
+    for m, t in enumerate(tris):
+        for v in t:
+            if fill[v] < 7:
+                pml[v, fill[v]] = m
+                fill[v] += 1
+    cfg.particleCount = pos.shape[0]
+    cfg.numOfElasticP = E
+    cfg.numOfMembranes = membranes.shape[0]
+    cfg.elasticOffset = 0
+    return dict(cfg=cfg, position=pos, velocity=vel, elastic=elastic, membranes=membranes, particle_membranes=pml,
+                numOfLiquidP=int(liq.shape[0]), numOfElasticP=E, numOfBoundaryP=int(bnd_p.shape[0]))
+
+
+# name -> builder. Sizes chosen so that the C oracle finishes 10 steps in well under a second.
+SCENES = {
+    "tiny": lambda: liquid_box((8.0, 8.0, 8.0), (12, 10, 12)),
+    "tiny_compressed": lambda: liquid_box((8.0, 8.0, 8.0), (13, 11, 13), spacing_in_r0=0.85),
+    "tiny_jitter": lambda: liquid_box((8.0, 6.0, 10.0), (12, 7, 15), jitter_in_r0=0.05),
+    "tiny_elastic": lambda: elastic_sheet_box(),
+    # shipped box (163,401 declared cells) with liquid at z > 672: raw cell ids exceed 16 bits, so reference mode
+    # aliases them onto low-z cells; ~105 k particles, mostly boundary shell
+    "alias16": lambda: liquid_box((30.0, 20.0, 250.0), (10, 8, 30), origin_in_r0=(3.0, 3.0, 415.0)),
+    # the same scene in wide mode (no aliasing)
+    "wide": lambda: liquid_box((30.0, 20.0, 250.0), (10, 8, 30), origin_in_r0=(3.0, 3.0, 415.0), mask=0xffffffff),
+}
+
+
+def config1():
+    """BASELINE config #1 inputs (configuration/positionPureLiquid.txt + velocityPureLiquid.txt), from the committed
+    fixture tests/golden/config1_input.npz (the text files live only in the build container)."""
+    z = np.load(os.path.join(GOLDEN, "config1_input.npz"))
+    cfg = sphmi.default_config()
+    cfg.particleCount = z["position"].shape[0]
+    return dict(cfg=cfg, position=z["position"], velocity=z["velocity"], elastic=None, membranes=None,
+                particle_membranes=None)
+
+
+def worm_scene_path():
+    return os.path.join(GOLDEN, "worm_input.npz")
+
+
+def worm_scene():
+    """BASELINE config #3: the output of the reference's own generator (owHelper::generateConfiguration), committed as
+    the fixture tests/golden/worm_input.npz by tests/golden/make_golden.py."""
+    z = np.load(worm_scene_path())
+    cfg = sphmi.default_config()
+    cfg.particleCount = int(z["position"].shape[0])
+    cfg.numOfElasticP = int(z["elastic"].shape[0] // 32)
+    cfg.numOfMembranes = int(z["membranes"].shape[0])
+    return dict(cfg=cfg, position=z["position"], velocity=z["velocity"], elastic=z["elastic"],
+                membranes=z["membranes"], particle_membranes=z["particle_membranes"])
+
+
+def oracle_for(scene, threads=4):
+    from oracle import oraclebind as O
+    return O.OracleSolver(sphmi.config_dict(scene["cfg"]), scene["position"], scene["velocity"], scene["elastic"],
+                          scene["membranes"], scene["particle_membranes"], threads=threads)
+
+
+def hip_for(scene):
+    return sphmi.owHIPSolver(scene["cfg"], scene["position"], scene["velocity"], scene["elastic"], scene["membranes"],
+                             scene["particle_membranes"])
+
+
+STAGE_SEQUENCE = (["clearBuffers", "hashParticles", "sort", "sortPostPass", "indexx", "indexPostPass", "findNeighbors",
+                   "computeDensity", "computeForcesAndInitPressure", "computeElasticForces"]
+                  + ["predictPositions", "predictDensity", "correctPressure", "computePressureForceAcceleration"] * 3
+                  + ["integrate", "clearMembraneBuffers", "computeInteractionWithMembranes",
+                     "computeInteractionWithMembranes_finalize"])
+
+HIP_STAGE_METHOD = {
+    "clearBuffers": "_runClearBuffers", "hashParticles": "_runHashParticles", "sort": "_runSort",
+    "sortPostPass": "_runSortPostPass", "indexx": "_runIndexx", "indexPostPass": "_runIndexPostPass",
+    "findNeighbors": "_runFindNeighbors", "computeDensity": "_run_pcisph_computeDensity",
+    "computeForcesAndInitPressure": "_run_pcisph_computeForcesAndInitPressure",
+    "computeElasticForces": "_run_pcisph_computeElasticForces", "predictPositions": "_run_pcisph_predictPositions",
+    "predictDensity": "_run_pcisph_predictDensity", "correctPressure": "_run_pcisph_correctPressure",
+    "computePressureForceAcceleration": "_run_pcisph_computePressureForceAcceleration",
+    "integrate": "_run_pcisph_integrate", "clearMembraneBuffers": "_run_clearMembraneBuffers",
+    "computeInteractionWithMembranes": "_run_computeInteractionWithMembranes",
+    "computeInteractionWithMembranes_finalize": "_run_computeInteractionWithMembranes_finalize"}
+
+
+def canonical(get, N):
+    """Reference-layout buffers -> the arrays parity is judged on. `get(name)` returns the flat buffer.
+    Dropped on purpose (dead data in the reference, never read by any kernel, not reproduced by the HIP path):
+    acceleration[].w (zeroed before use, sphFluid.cl:1721) and the .w of the predicted half of sortedPosition."""
+    out = {}
+    pos = get("position").reshape(-1, 4)
+    out["position"] = pos[:N]
+    out["membraneScratch"] = pos[N:, :3]
+    out["velocity"] = get("velocity").reshape(-1, 4)[:N]
+    sp = get("sortedPosition").reshape(-1, 4)
+    out["sortedPosition"] = sp[:N]
+    out["predictedPosition"] = sp[N:, :3]
+    out["sortedVelocity"] = get("sortedVelocity").reshape(-1, 4)
+    out["acceleration"] = get("acceleration").reshape(-1, 4)[:, :3]
+    nm = get("neighborMap").reshape(-1, 2)
+    out["neighborIds"] = nm[:, 0].astype(np.int32)
+    out["neighborDist"] = nm[:, 1]
+    for b in ("particleIndex", "particleIndexBack", "gridCellIndex", "gridCellIndexFixedUp", "pressure", "rho"):
+        out[b] = get(b)
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype.itemsize != b.dtype.itemsize:
+        return False
+    return bool((a.view(np.uint8) == b.view(np.uint8)).all())
+
+
+def diff_report(a, b):
+    a = np.ascontiguousarray(a).ravel()
+    b = np.ascontiguousarray(b).ravel()
+    if a.shape != b.shape:
+        return "shape %s vs %s" % (a.shape, b.shape)
+    ne = a.view(np.uint32) != b.view(np.uint32)
+    idx = np.flatnonzero(ne)
+    if idx.size == 0:
+        return "equal"
+    i = int(idx[0])
+    return "%d of %d words differ; first at %d: %r vs %r" % (idx.size, a.size, i, a[i], b[i])

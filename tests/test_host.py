@@ -1,0 +1,145 @@
+"""CPU tests of the host layer: constants pinned to the reference compiler's evaluation, loaders, scene helpers,
+and that both shared libraries load and export every symbol the headers declare (no compute calls without a GPU)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scenes
+import sphmi
+
+GOLDEN = scenes.GOLDEN
+
+
+def test_constants_match_reference_compiler():
+    """include/sphmi_host.h: sphmi_default_config == owPhysicsConstant.h as evaluated by the reference build
+    (tests/golden/constants.json, written by make_golden.py from oracle/_ref)."""
+    ref = json.load(open(os.path.join(GOLDEN, "constants.json")))
+    cfg = sphmi.default_config()
+    for name, bits in ref["float_bits"].items():
+        if name in ("stiffness", "damping"):  # passed to kernels but never used in arithmetic
+            continue
+        got = int(np.float32(getattr(cfg, name)).view(np.uint32))
+        assert got == bits, "%s: %08x != %08x" % (name, got, bits)
+    for name, hx in ref["double_hex"].items():
+        if name == "beta":
+            continue
+        assert float(getattr(cfg, name)).hex() == hx, name
+    for name in ("gridCellsX", "gridCellsY", "gridCellsZ", "gridCellCount", "maxIteration"):
+        assert getattr(cfg, name) == ref[name]
+    # pinned bit patterns of SURVEY Appendix A
+    assert int(np.float32(cfg.delta).view(np.uint32)) == 0x3E80422C
+    assert int(np.float32(cfg.simulationScale).view(np.uint32)) == 0x3607FBE2
+    assert (cfg.gridCellsX, cfg.gridCellsY, cfg.gridCellsZ, cfg.gridCellCount) == (31, 21, 251, 163401)
+
+
+def test_surface_tension_coefficient_matches_oracle():
+    from oracle import oraclebind as O
+    cfg = sphmi.default_config()
+    want = O.lib().sph_oracle_surf_tens_coeff(cfg.Wpoly6Coefficient, cfg.h, cfg.simulationScale)
+    assert np.float32(cfg.surfTensCoeff).view(np.uint32) == np.float32(want).view(np.uint32)
+
+
+def test_box_generator_reproduces_reference_boundary_shell():
+    """The boundary part of sphmi_generate_box == the last numOfBoundaryP particles of the reference generator's
+    output (tests/golden/worm_input.npz), bit for bit: positions, normals stored in velocity, type 3 in both .w."""
+    w = np.load(os.path.join(GOLDEN, "worm_input.npz"))
+    cfg = sphmi.default_config()
+    pos, vel, cnt = sphmi.generate_box(cfg, 0, 0, 0)
+    nb = cnt["numOfBoundaryP"]
+    assert nb == 102408
+    assert scenes.bits_equal(pos, w["position"][-nb:])
+    assert scenes.bits_equal(vel, w["velocity"][-nb:])
+
+
+def test_box_sizes_of_survey_configs():
+    """config #2 N=1,058,808 (grid 51^3), config #4 N=16,507,704, config #5 N=65,469,208."""
+    for box, lat, n, grid in (((50.0, 50.0, 50.0), (100, 100, 100), 1058808, (51, 51, 51)),
+                              ((78.0, 50.0, 470.0), (160, 100, 1000), 16507704, (79, 51, 471)),
+                              ((240.0, 200.0, 310.0), (250, 400, 640), 65469208, (241, 201, 311))):
+        cfg = sphmi.default_config()
+        sphmi.set_box(cfg, *box, 0xffffffff)
+        nl, nb = ctypes.c_int(), ctypes.c_int()
+        assert sphmi.host_lib().sphmi_box_counts(ctypes.byref(cfg), box[0], box[1], box[2], lat[0], lat[1], lat[2],
+                                                 ctypes.byref(nl), ctypes.byref(nb)) == 0
+        assert nl.value + nb.value == n
+        assert (cfg.gridCellsX, cfg.gridCellsY, cfg.gridCellsZ) == grid
+
+
+def test_text_loader_roundtrip(tmp_path):
+    """owHelper::preLoadConfiguration/loadConfiguration format: `x y z type` per line, tab separated %e,
+    last line without a newline is still a particle (owHelper.cpp:1441-1447)."""
+    z = np.load(os.path.join(GOLDEN, "config1_input.npz"))
+    pos, vel = z["position"][:300], z["velocity"][:300]
+    pf, vf = tmp_path / "position.txt", tmp_path / "velocity.txt"
+    pf.write_text("\n".join("\t".join("%e" % v for v in row) for row in pos))
+    vf.write_text("\n".join("\t".join("%e" % v for v in row) for row in vel) + "\n")
+    p2, v2, cnt = sphmi.load_configuration(str(pf), str(vf))
+    assert p2.shape == (300, 4) and cnt["numOfBoundaryP"] + cnt["numOfLiquidP"] == 300
+    np.testing.assert_allclose(p2, pos, rtol=1e-6)
+    np.testing.assert_allclose(v2, vel, rtol=1e-6, atol=1e-12)
+    with pytest.raises(sphmi.SphError):
+        sphmi.load_configuration(str(tmp_path / "missing.txt"), str(vf))
+
+
+def test_muscle_signal_closed_form():
+    """main_sim.py:4-53 in closed form (parity unpinned: the Python-2 script cannot run here; formula by inspection)."""
+    s0 = sphmi.muscle_signal(0)
+    assert s0.shape == (100,) and np.all(s0[96:] == 0)
+    k = np.repeat(np.arange(12), 2)
+    w1 = (np.sin(k * 3 * np.pi / 11) + 1) / 2
+    w2 = (np.sin(k * 3 * np.pi / 11 + np.pi) + 1) / 2
+    np.testing.assert_allclose(s0[:96], np.concatenate([w1, w2, w2, w1]), atol=1e-7)
+    s5 = sphmi.muscle_signal(50000)
+    assert np.abs(s5[:96] - s0[:96]).max() > 0.1  # the wave travels
+
+
+def _declared(header, prefix):
+    txt = open(os.path.join(scenes.ROOT, "include", header)).read()
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, txt)))
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(sphmi.HOST_LIB_PATH)
+    names = _declared("sphmi_host.h", "sphmi_")
+    assert set(names) == set(sphmi.HOST_EXPORTED_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_device_library_loads_and_exports_every_declared_symbol():
+    """libsphmi.so must load on a machine without a GPU (symbols only; no compute call is made here)."""
+    lib = ctypes.CDLL(sphmi.LIB_PATH)
+    names = [n for n in _declared("sphmi.h", "sph_") if n not in ("sph_status", "sph_stage")]
+    assert set(names) == set(sphmi.EXPORTED_SYMBOLS), set(names) ^ set(sphmi.EXPORTED_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.sph_abi_version.restype = ctypes.c_int
+    assert lib.sph_abi_version() == sphmi.ABI_VERSION
+
+
+def test_create_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a HIP device the constructor raises (SPH_ERR_HIP) instead of computing."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sc = scenes.SCENES["tiny"]()
+    with pytest.raises(sphmi.SphError):
+        scenes.hip_for(sc)
+
+
+def test_config_struct_layout_matches_header():
+    """ctypes mirror of sph_config has the size the C compiler gives the header's struct."""
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "sphmi.h"\nint main(){printf("%zu %zu\\n", sizeof(sph_config), __builtin_offsetof(sph_config, stream));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(scenes.ROOT, "include"), c, "-o", exe])
+        size, off = map(int, subprocess.check_output([exe]).split())
+    assert ctypes.sizeof(sphmi.SphConfig) == size
+    assert sphmi.SphConfig.stream.offset == off
