@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/s of the PCISPH step path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full simulationStep() (owPhysicsFluidSimulator.cpp:79-149: neighbour search + PCISPH predict-correct
+loop + integration) of BASELINE config #2, the 1M-particle pure-liquid cube of SURVEY §8(d) (N = 1,058,808 including
+the boundary shell, reference-exact 16-bit cell ids), through the C ABI of libsphmi.so with all state resident in HBM.
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline      the density pass (pcisph_computeDensity): algorithmic bytes = 132 B/particle (32 distances + 1 write,
+                SURVEY §8d) / its mean launch duration, measured with HIP events on the solver's stream inside real steps
+  cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores on the same scene, few steps
+  stages_ms     mean device time per stage per step (HIP events), findNeighbors reported as time
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DENSITY_BYTES_PER_PARTICLE = 132  # 32 x 4 B distances read + 4 B density written
+
+WORKLOADS = {
+    # name: (box in h, liquid lattice, cell id mask)
+    "config2_1M_cube": ((50.0, 50.0, 50.0), (100, 100, 100), 0xffff),
+    "tiny": ((8.0, 8.0, 8.0), (12, 10, 12), 0xffff),
+    "cube_4M": ((80.0, 80.0, 80.0), (160, 160, 160), 0xffffffff),
+}
+
+
+def host_cores():
+    """Threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota and by the GPU box's
+    per-GPU CPU share (16), overridable with SPHMI_CPU_THREADS."""
+    if os.environ.get("SPHMI_CPU_THREADS"):
+        return max(1, int(os.environ["SPHMI_CPU_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2_1M_cube", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-stage-pass", action="store_true", help="skip the second, per-stage-timed pass")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import scenes
+    import sphmi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libsphmi has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    box, lattice, mask = WORKLOADS[args.workload]
+    sc = scenes.liquid_box(box, lattice, mask=mask)
+    cfg = sc["cfg"]
+    cfg.device = local_rank
+    stream = torch.cuda.Stream(device=local_rank)
+    cfg.stream = stream.cuda_stream  # the solver launches on this stream; torch events below are recorded on it
+    N = cfg.particleCount
+    solver = sphmi.owHIPSolver(cfg, sc["position"], sc["velocity"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        solver.step(it); it += 1
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+        for _ in range(args.steps):
+            solver.step(it); it += 1
+        ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    value = N * world * args.steps / wall
+
+    # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
+    stages_ms, roofline = {}, None
+    if not args.no_stage_pass:
+        solver.set_stage_timing(True)
+        solver.reset_stage_times()
+        k2 = max(5, min(args.steps, 20))
+        for _ in range(k2):
+            solver.step(it); it += 1
+        st = solver.stage_times()
+        solver.set_stage_timing(False)
+        stages_ms = {k: round(ms / k2, 5) for k, (ms, cnt) in st.items() if cnt}
+        d_ms, d_cnt = st["density"]
+        if d_cnt:
+            achieved = N * DENSITY_BYTES_PER_PARTICLE / (d_ms / d_cnt * 1e-3) / 1e9
+            roofline = {"kernel": "k_density (pcisph_computeDensity)", "bound": "hbm", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "avg_launch_us": round(d_ms / d_cnt * 1e3, 2),
+                        "bytes_per_launch": N * DENSITY_BYTES_PER_PARTICLE}
+            traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
+            if os.path.exists(traffic_file):  # PMC result of the committed rocprofv3 passes (see profiles/README.md)
+                tr = json.load(open(traffic_file))
+                if tr.get("workload") == args.workload:
+                    roofline["traffic"] = tr.get("hbm_bytes_per_launch")
+
+    # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
+    cpu = None
+    if rank == 0 and args.cpu_steps > 0:
+        cores = host_cores()
+        ora = scenes.oracle_for(sc, threads=cores)
+        ora.step()  # warm-up (page faults, first-touch)
+        c0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            ora.step()
+        cw = time.perf_counter() - c0
+        cpu = {"value": round(N * args.cpu_steps / cw, 1), "unit": "particle-steps/s", "cores": cores, "kind": "port",
+               "sample": "%d steps of the same %d-particle scene after 1 warm-up step (oracle/sph_oracle.c, OpenMP)"
+                         % (args.cpu_steps, N), "ms_per_step": round(cw * 1e3 / args.cpu_steps, 2)}
+        ora.close()
+
+    solver.close()
+    if rank == 0:
+        out = {
+            "metric": "particle-steps/sec (whole node)", "value": round(value, 1), "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "particles_per_gpu": N, "box_in_h": list(box),
+                       "liquid_lattice": list(lattice), "cell_ids": "ref16" if mask == 0xffff else "wide",
+                       "pcisph_iterations": cfg.maxIteration,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent boxes (replicas, no halo yet)" % world},
+            "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = round(value / world / cpu["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,49 +129,43 @@ int sphk_sort(sph_solver* s) {
 }
 
 // ------------------------------------------------------------------ K3 sortPostPass (sphFluid.cl:441-466)
-// + K4 indexx (sphFluid.cl:385-439) + host fix-up (owOpenCLSolver.cpp:305-319).
-// cellStart[c] = number of particles whose cell id is < c: for a non-empty cell its first sorted index, for an empty
-// one the start of the next non-empty cell, [0] = 0, [G] = N — exactly the fixed-up table. Every thread whose key
-// differs from its predecessor's fills the run of cells in between, so no binary search and no host pass are needed.
-template <bool GATHER, bool INDEX>
 __global__ __launch_bounds__(SPH_BLOCK) void k_sort_post(SphDev d) {
   const int i = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (i >= d.N) return;
-  const uint32_t key = d.keys[i];
-  if (GATHER) {
-    const uint32_t src = d.vals[i];
-    d.sortedPos[i] = d.posOrig[src];  // .w stays the particle type; the cell id lives in keys[]
-    d.sortedVel[i] = d.velOrig[src];
-    d.backIndex[src] = (uint32_t)i;
+  const uint32_t src = d.vals[i];
+  d.sortedPos[i] = d.posOrig[src];  // .w stays the particle type; the cell id lives in keys[]
+  d.sortedVel[i] = d.velOrig[src];
+  d.backIndex[src] = (uint32_t)i;
+}
+
+// K4 indexx (sphFluid.cl:385-439) + the host fix-up loop (owOpenCLSolver.cpp:305-319) in one kernel, one lane per cell:
+// cellStart[c] = number of particles whose cell id is < c (lower bound in the sorted keys). For a non-empty cell that
+// is its first sorted index (what the reference's binary search finds); for an empty one it is the start of the next
+// non-empty cell (what the backward fill writes); [0] = 0 and [G] = N. The key array is L2-resident (4 B/particle).
+__global__ __launch_bounds__(SPH_BLOCK) void k_cell_start(SphDev d) {
+  const int c = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (c > d.G) return;
+  int lo = 0, hi = d.N;  // first index in [0, N] whose key is >= c
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (d.keys[mid] < (uint32_t)c) lo = mid + 1; else hi = mid;
   }
-  if (INDEX) {
-    const uint32_t G = (uint32_t)d.G;
-    if (i == 0) {
-      for (uint32_t c = 0; c <= min(key, G); c++) d.cellStart[c] = 0u;
-    } else {
-      const uint32_t prev = d.keys[i - 1];
-      if (prev != key)
-        for (uint32_t c = prev + 1; c <= min(key, G); c++) d.cellStart[c] = (uint32_t)i;
-    }
-    if (i == d.N - 1)
-      for (uint32_t c = key + 1; c <= G; c++) d.cellStart[c] = (uint32_t)d.N;
-  }
+  d.cellStart[c] = (c == d.G) ? (uint32_t)d.N : (uint32_t)lo;
 }
 
 int sphk_sort_post(sph_solver* s) {
-  hipLaunchKernelGGL((k_sort_post<true, false>), dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  hipLaunchKernelGGL(k_sort_post, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
 int sphk_index_fixed(sph_solver* s) {
-  hipLaunchKernelGGL((k_sort_post<false, true>), dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  hipLaunchKernelGGL(k_cell_start, dim3(sph_blocks(s->d.G + 1)), dim3(SPH_BLOCK), 0, s->stream, s->d);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
 int sphk_sort_post_and_index(sph_solver* s) {
-  hipLaunchKernelGGL((k_sort_post<true, true>), dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
-  SPH_HIP(hipGetLastError());
-  return SPH_OK;
+  int rc = sphk_sort_post(s);
+  return rc == SPH_OK ? sphk_index_fixed(s) : rc;
 }
 
 // K4 alone, for stage-by-stage parity: first sorted index of each non-empty cell, 0xffffffff (NO_PARTICLE_ID) for empty

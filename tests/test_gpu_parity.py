@@ -17,6 +17,9 @@ import sphmi
 pytestmark = pytest.mark.gpu
 
 POSITION_RTOL = 1e-5  # north_star: "particle positions within 1e-5 relative after N steps"
+# K4's intermediate table (first index per cell, -1 for empty cells) is only materialised by sph_run_indexx();
+# the fused sph_step() writes the fixed-up table directly (sph_sort.hip, k_sort_post), so it is not compared there.
+FUSED_SKIP = ("gridCellIndex",)
 
 
 def canon_hip(h, N):
@@ -59,8 +62,12 @@ def test_stage_by_stage_matches_oracle(name):
                 ora.run(st)
                 if big and st not in ("sort", "indexPostPass", "findNeighbors", "computeDensity", "integrate"):
                     continue
-                # staged-mode note: without elastic matter the membrane kernels' `+= 0` is folded into integrate
-                assert_same(canon_hip(hip, N), canon_ora(ora, N), "%s step %d stage %d %s" % (name, it, k, st))
+                # The export rebuilds sortedPosition.w (the cell id) from the key array, which hashParticles and sort
+                # rewrite before sortPostPass refreshes sortedPosition: skip that one buffer for those two stages.
+                skip = ("sortedPosition",) if st in ("hashParticles", "sort") else ()
+                if k < scenes.STAGE_SEQUENCE.index("indexx"):
+                    skip += FUSED_SKIP  # still the table of the last *staged* step until indexx runs again
+                assert_same(canon_hip(hip, N), canon_ora(ora, N), "%s step %d stage %d %s" % (name, it, k, st), skip)
         else:
             hip.step(it)
             ora.step()
@@ -68,7 +75,7 @@ def test_stage_by_stage_matches_oracle(name):
             sig = sphmi.muscle_signal(it)
             hip.updateMuscleActivityData(sig)
             ora.update_muscles(sig)
-        assert_same(canon_hip(hip, N), canon_ora(ora, N), "%s after step %d" % (name, it))
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "%s after step %d" % (name, it), () if staged else FUSED_SKIP)
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_compressed", "tiny_jitter", "tiny_elastic"])
@@ -89,7 +96,7 @@ def test_fused_step_matches_reference_fixture(name):
                 assert scenes.bits_equal(c[key], z["%s_%d" % (key, it)]), \
                     "%s %s after step %d: %s" % (name, key, it, scenes.diff_report(c[key], z["%s_%d" % (key, it)]))
             got = {b: scenes.sha(v) for b, v in c.items()}
-            bad = [b for b in got if got[b] != meta["step_hashes"][str(it)][b]]
+            bad = [b for b in got if got[b] != meta["step_hashes"][str(it)][b] and b not in FUSED_SKIP]
             assert not bad, (name, it, bad)
     err = position_rel_err(hip.read_position_buffer(), z["position_10"], sc["cfg"].r0)
     assert err <= POSITION_RTOL
@@ -110,7 +117,7 @@ def test_config1_100_steps_against_reference_fixture():
             err = position_rel_err(pos[z["sample_ids"]], want, sc["cfg"].r0)
             assert err <= POSITION_RTOL, "step %d: rel err %g" % (it, err)
             got = {b: scenes.sha(v) for b, v in canon_hip(sim.ocl_solver, N).items()}
-            bad = [b for b in got if got[b] != meta["step_hashes"][str(it)][b]]
+            bad = [b for b in got if got[b] != meta["step_hashes"][str(it)][b] and b not in FUSED_SKIP]
             assert not bad, "config1 step %d: %s differ from the reference" % (it, bad)
 
 
@@ -128,7 +135,7 @@ def test_worm_scene_against_reference_fixture():
             err = position_rel_err(sim.getPosition_cpp()[z["sample_ids"]], z["position_sample_%d" % it], sc["cfg"].r0)
             assert err <= POSITION_RTOL, "step %d: rel err %g" % (it, err)
             got = {b: scenes.sha(v) for b, v in canon_hip(sim.ocl_solver, N).items()}
-            bad = [b for b in got if got[b] != meta["step_hashes"][str(it)][b]]
+            bad = [b for b in got if got[b] != meta["step_hashes"][str(it)][b] and b not in FUSED_SKIP]
             assert not bad, "worm step %d: %s differ from the reference" % (it, bad)
 
 
@@ -212,7 +219,7 @@ def test_ragged_sizes_and_single_particle_cells():
         for it in range(3):
             hip.step(it)
             ora.step()
-        assert_same(canon_hip(hip, N), canon_ora(ora, N), "lattice %s" % (lattice,))
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "lattice %s" % (lattice,), FUSED_SKIP)
 
 
 def test_error_behaviour():
