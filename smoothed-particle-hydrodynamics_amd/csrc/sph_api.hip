@@ -85,6 +85,7 @@ extern "C" int sph_set_stage_timing(sph_solver* s, int enable) {
 extern "C" int sph_reset_stage_times(sph_solver* s) {
   if (!s) return SPH_ERR_INVALID;
   int rc = resolve_pending(s);
+  hipMemsetAsync(s->d.dbg, 0, sizeof(uint32_t) * 16, s->stream);
   memset(s->stageMs, 0, sizeof(s->stageMs));
   memset(s->stageLaunches, 0, sizeof(s->stageLaunches));
   return rc;
@@ -105,7 +106,7 @@ static void free_all(sph_solver* s) {
   SphDev& d = s->d;
   void* ptrs[] = {d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
                   d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho, d.rhoPred,
-                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, s->blockHist};
+                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
   free(s->pending);
@@ -200,6 +201,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.nbrId, mapN); A(d.nbrDist, mapN);
   A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
   A(s->blockHist, (size_t)256 * s->sortBlocks);
+  A(d.dbg, 16);
   if (d.hasElastic) {
     A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);
     if (membraneData && pml && cfg->numOfMembranes > 0) { A(d.membraneData, (size_t)3 * cfg->numOfMembranes); A(d.pml, (size_t)7 * d.numElastic); }
@@ -231,6 +233,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   hipMemsetAsync(d.pressure, 0, sizeof(float) * n, s->stream);
   hipMemsetAsync(d.nbrId, 0xff, sizeof(int32_t) * mapN, s->stream);
   hipMemsetAsync(d.nbrDist, 0, sizeof(float) * mapN, s->stream);
+  hipMemsetAsync(d.dbg, 0, sizeof(uint32_t) * 16, s->stream);
   hipMemsetAsync(d.cellStartRaw, 0, sizeof(uint32_t) * G1, s->stream);
   hipMemsetAsync(d.cellStart, 0, sizeof(uint32_t) * G1, s->stream);
   hipMemsetAsync(d.sortedPos, 0, sizeof(float4) * n, s->stream);
@@ -448,7 +451,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   const SphDev& d = s->d;
   const size_t n = (size_t)d.N, G1 = (size_t)d.G + 1;
   size_t need = 0;
-  enum { B_POS, B_VEL, B_SPOS, B_SVEL, B_ACC, B_NMAP, B_NIDS, B_PI, B_PIB, B_GCI, B_GCIF, B_P, B_RHO } which;
+  enum { B_POS, B_VEL, B_SPOS, B_SVEL, B_ACC, B_NMAP, B_NIDS, B_PI, B_PIB, B_GCI, B_GCIF, B_P, B_RHO, B_DBG } which;
   if (!strcmp(name, "position")) { which = B_POS; need = sizeof(float4) * 2 * n; }
   else if (!strcmp(name, "velocity")) { which = B_VEL; need = sizeof(float4) * 2 * n; }
   else if (!strcmp(name, "sortedPosition")) { which = B_SPOS; need = sizeof(float4) * 2 * n; }
@@ -462,6 +465,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   else if (!strcmp(name, "gridCellIndexFixedUp")) { which = B_GCIF; need = sizeof(uint32_t) * G1; }
   else if (!strcmp(name, "pressure")) { which = B_P; need = sizeof(float) * n; }
   else if (!strcmp(name, "rho")) { which = B_RHO; need = sizeof(float) * 2 * n; }
+  else if (!strcmp(name, "debugCounters")) { which = B_DBG; need = sizeof(uint32_t) * 16; }
   else { sph_set_error("unknown buffer '%s'", name); return SPH_ERR_UNKNOWN_BUFFER; }
   if (needed) *needed = need;
   if (!out) return SPH_OK;
@@ -520,6 +524,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
     case B_GCI: rc = d2h(s, o, d.cellStartRaw, sizeof(uint32_t) * G1); break;
     case B_GCIF: rc = d2h(s, o, d.cellStart, sizeof(uint32_t) * G1); break;
     case B_P: rc = d2h(s, o, d.pressure, sizeof(float) * n); break;
+    case B_DBG: rc = d2h(s, o, d.dbg, sizeof(uint32_t) * 16); break;
     case B_RHO:
       rc = d2h(s, o, d.rho, sizeof(float) * n);
       if (rc == SPH_OK) rc = d2h(s, o + sizeof(float) * n, d.rhoPred, sizeof(float) * n);

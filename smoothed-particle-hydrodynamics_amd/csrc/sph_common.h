@@ -52,6 +52,7 @@ struct SphDev {  // what the kernels see; passed by value
   float4* elastic;
   int32_t *membraneData, *pml;
   float* muscle;
+  uint32_t* dbg;  // 16 diagnostic counters (neighbour-search fallbacks etc.), zeroed by sph_reset_stage_times
 };
 
 struct sph_solver {
