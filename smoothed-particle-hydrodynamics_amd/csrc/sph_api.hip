@@ -200,7 +200,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
   A(d.nbrId, mapN); A(d.nbrDist, mapN);
   A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
-  A(s->blockHist, (size_t)256 * s->sortBlocks);
+  A(s->blockHist, (size_t)256 * s->sortBlocks + 256);  // [256][sortBlocks] block histograms + 256 digit totals
   A(d.dbg, 16);
   if (d.hasElastic) {
     A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);

@@ -147,7 +147,7 @@ struct FnShared {
 // Lane pair (2p, 2p+1) serves particle p: lane `half` walks the cells k = half, half+2, half+4, half+6 of the
 // reference's order, so the merged traversal order is A0 B1 A2 B3 A4 B5 A6 B7 and only four per-cell hit counts have
 // to cross lanes (one DPP swap each) to place every neighbour in the reference's slot.
-__global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint32_t* __restrict__ slowQueue) {
+__global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint32_t* __restrict__ slowQueue, int experiment) {
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
   const int tid = threadIdx.x;
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
   __syncthreads();
 
+  if (experiment == 1) return;  // timing experiment: staging only
   float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
   bool slow = false;
   int ldsLo[4], num[4];
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     segEnd[i] = cnt;
   }
 #undef FN_VISIT
+  if (experiment == 2) { if (cnt == 12345) d.dbg[15] = 1; return; }  // timing experiment: staging + walk
   bool over = cnt > FN_LIST_CAP;
   over = over || (__shfl_xor((int)over, 1) != 0);
   if (over) {
@@ -257,15 +259,38 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     for (int i = 0; i < 4; i++) segEnd[i] = 0;
   }
 
-  // ---- 2a. pass 0 of the reference over the lists: per-particle 30-bin histogram of hits with d^2 <= h^2
+  // ---- 2. replay of the reference's two passes over the short lists, entirely in registers.
+  // The list (<= 48 LDS slots per lane) is expanded once into d2[] / idx[] with static indices: all list reads, then all
+  // candidate reads are in flight together, and pass 0 (histogram), the threshold and pass 1 (selection + slot
+  // assignment) never touch LDS for candidate data again.
+  const int total = segEnd[3];
+  float d2v[FN_LIST_CAP];
+  int idxv[FN_LIST_CAP];
+#pragma unroll
+  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 16) {
+    if (__any(c0 < total)) {  // wave-uniform skip of empty 16-entry chunks
+      uint32_t slot[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) slot[u] = min((uint32_t)sh.list[c0 + u][tid], (uint32_t)(FN_CAND_CAP + FN_CAND_PAD - 1));
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const float4 o = sh.cand[slot[u]];
+        const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
+        d2v[c0 + u] = ex * ex + ey * ey + ez * ez;
+        idxv[c0 + u] = __float_as_int(o.w);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; u++) { d2v[c0 + u] = 0.f; idxv[c0 + u] = -1; }
+    }
+  }
+  // ---- 2a. pass 0: per-particle 30-bin histogram of the hits with d^2 <= h^2 (sphFluid.cl:157-161)
   for (int w = half; w < FN_HIST_WORDS; w += 2) sh.hist[w][p] = 0u;
   const float h2 = d.h * d.h;
-  for (int e = 0; e < segEnd[3]; e++) {
-    const float4 o = sh.cand[sh.list[e][tid]];
-    const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-    const float d2 = ex * ex + ey * ey + ez * ez;
-    if (d2 <= h2) {
-      const float dist = sqrtf(d2);
+#pragma unroll
+  for (int e = 0; e < FN_LIST_CAP; e++) {
+    if (e < total && d2v[e] <= h2) {
+      const float dist = sqrtf(d2v[e]);
       const int bin = (int)(dist * (float)SPH_RSEG / d.h);
       if (bin < SPH_RSEG) atomicAdd(&sh.hist[bin >> 1][p], 1u << ((bin & 1) << 4));
     }
@@ -280,50 +305,48 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
   const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
   const float r2 = r_thr * r_thr;
+  if (experiment == 3) { if (r2 == 12345.f) d.dbg[15] = 1; return; }  // timing experiment: + histogram pass
 
-  // ---- 2b. pass 1: count the hits with d^2 <= r_thr^2 per cell, swap the counts inside the pair, then write every
-  // hit at (hits in earlier cells of the merged order) + (rank inside its cell); slots >= 32 are dropped, which is what
-  // the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
-  int mine[4], theirs[4];
-  {
-    int e = 0;
+  // ---- 2b. pass 1: hits with d^2 <= r_thr^2. Count them per cell, swap the four counts inside the pair, then write
+  // every hit at (hits in earlier cells of the merged order) + (rank inside its cell); slots >= 32 are dropped, which is
+  // what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
+  int mine[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int c = 0;
-      for (; e < segEnd[i]; e++) {
-        const float4 o = sh.cand[sh.list[e][tid]];
-        const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-        const float d2 = ex * ex + ey * ey + ez * ez;
-        c += (d2 <= r2) ? 1 : 0;
-      }
-      mine[i] = c;
-    }
+  for (int e = 0; e < FN_LIST_CAP; e++) {
+    const int acc = (e < total && d2v[e] <= r2) ? 1 : 0;
+    mine[0] += (e < segEnd[0]) ? acc : 0;
+    mine[1] += (e >= segEnd[0] && e < segEnd[1]) ? acc : 0;
+    mine[2] += (e >= segEnd[1] && e < segEnd[2]) ? acc : 0;
+    mine[3] += (e >= segEnd[2]) ? acc : 0;
   }
+  int theirs[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) theirs[i] = __shfl_xor(mine[i], 1);
   if (alive && !slow) {
     int start[4], run = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {  // merged order: (lane 0, i), (lane 1, i), (lane 0, i+1), ...
-      if (half == 0) { start[i] = run; run += mine[i] + theirs[i]; }
-      else { start[i] = run + theirs[i]; run += mine[i] + theirs[i]; }
+      start[i] = run + (half ? theirs[i] : 0);
+      run += mine[i] + theirs[i];
     }
-    int e = 0;
+    if (experiment == 5) { if (run == 12345) d.dbg[15] = 1; return; }  // timing experiment: no write loop
+    // position of entry e = start of its cell + hits before it inside the cell
+    int pos = start[0];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int pos = start[i];
-      for (; e < segEnd[i]; e++) {
-        const float4 o = sh.cand[sh.list[e][tid]];
-        const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-        const float d2 = ex * ex + ey * ey + ez * ez;
-        if (d2 <= r2) {
-          if (pos < SPH_MAXN) {
-            const size_t idx = nbr_index(id, pos);
-            d.nbrId[idx] = __float_as_int(o.w);
-            d.nbrDist[idx] = sqrtf(d2) * d.simScale;
+    for (int e = 0; e < FN_LIST_CAP; e++) {
+      if (e == segEnd[0]) pos = start[1];  // (segments may be empty: later assignments win, in order)
+      if (e == segEnd[1]) pos = start[2];
+      if (e == segEnd[2]) pos = start[3];
+      if (e < total && d2v[e] <= r2) {
+        if (pos < SPH_MAXN) {
+          const size_t idx = nbr_index(id, pos);
+          if (experiment == 4) { if (sqrtf(d2v[e]) * d.simScale == 12345.f) d.dbg[15] = idxv[e]; }
+          else {
+            d.nbrId[idx] = idxv[e];
+            d.nbrDist[idx] = sqrtf(d2v[e]) * d.simScale;
           }
-          pos++;
         }
+        pos++;
       }
     }
     for (int k = min(run, SPH_MAXN) + half; k < SPH_MAXN; k += 2) {  // K1 folded in: unused slots = (-1, -1)
@@ -354,8 +377,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_v1(SphDev d) {
 }
 
 int sphk_find_neighbors(sph_solver* s) {
-  static int variant = -1;
+  static int variant = -1, experiment = 0;
   if (variant < 0) {
+    const char* x = getenv("SPHMI_FN_EXPERIMENT");
+    experiment = x ? atoi(x) : 0;
     const char* e = getenv("SPHMI_FIND_NEIGHBORS");
     variant = (e && !strcmp(e, "v1")) ? 1 : 2;
   }
@@ -369,7 +394,7 @@ int sphk_find_neighbors(sph_solver* s) {
     }
     // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
     SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
-    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, s->d, s->d.keysAlt);
+    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, s->d, s->d.keysAlt, experiment);
     hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N), 2048)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
   }
   SPH_HIP(hipGetLastError());

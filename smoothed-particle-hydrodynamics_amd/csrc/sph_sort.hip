@@ -43,35 +43,52 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_hist(const uint32_t* __rest
   blockHist[(size_t)threadIdx.x * numBlocks + blockIdx.x] = hist[threadIdx.x];
 }
 
-// exclusive scan of blockHist[256*numBlocks] (digit-major) by a single 1024-thread block
-__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ blockHist, int total) {
-  __shared__ uint32_t part[1024];
-  const int per = (total + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = min(lo + per, total);
+// Offsets in two levels, no single-block pass over the whole table:
+//   k_radix_scan_rows: one workgroup per digit turns that digit's row blockHist[digit][0..numBlocks) into an exclusive
+//                      scan in place and leaves the row total in digitTotal[digit];
+//   k_radix_scatter:   every workgroup scans the 256 digit totals itself (LDS) to get the digit bases.
+__global__ __launch_bounds__(SPH_BLOCK) void k_radix_scan_rows(uint32_t* __restrict__ blockHist, int numBlocks,
+                                                                uint32_t* __restrict__ digitTotal) {
+  __shared__ uint32_t part[SPH_BLOCK];
+  uint32_t* row = blockHist + (size_t)blockIdx.x * numBlocks;
+  const int per = (numBlocks + SPH_BLOCK - 1) / SPH_BLOCK;
+  const int lo = min((int)threadIdx.x * per, numBlocks), hi = min(lo + per, numBlocks);
   uint32_t sum = 0;
-  for (int i = lo; i < hi; i++) sum += blockHist[i];
+  for (int i = lo; i < hi; i++) sum += row[i];
   part[threadIdx.x] = sum;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+  for (int off = 1; off < SPH_BLOCK; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+    const uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
     __syncthreads();
     part[threadIdx.x] += v;
     __syncthreads();
   }
   uint32_t run = part[threadIdx.x] - sum;
-  for (int i = lo; i < hi; i++) { uint32_t v = blockHist[i]; blockHist[i] = run; run += v; }
+  for (int i = lo; i < hi; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
+  if (threadIdx.x == SPH_BLOCK - 1) digitTotal[blockIdx.x] = part[SPH_BLOCK - 1];
 }
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __restrict__ keysIn,
                                                               const uint32_t* __restrict__ valsIn,
                                                               uint32_t* __restrict__ keysOut,
                                                               uint32_t* __restrict__ valsOut, int N, int shift,
-                                                              const uint32_t* __restrict__ blockHist, int numBlocks) {
+                                                              const uint32_t* __restrict__ blockHist, int numBlocks,
+                                                              const uint32_t* __restrict__ digitTotal) {
   __shared__ volatile uint32_t waveCount[4][256];  // running count of digit d inside wave w's range
-  __shared__ uint32_t digitBase[4][256];  // global output index of the first key with digit d of wave w
+  __shared__ uint32_t digitBase[4][256];           // global output index of the first key with digit d of wave w
+  __shared__ uint32_t scan[256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 4 * 256; i += SPH_BLOCK) waveCount[i >> 8][i & 255] = 0;
+  const uint32_t myTotal = digitTotal[threadIdx.x];
+  scan[threadIdx.x] = myTotal;
   __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the 256 digit totals
+    const uint32_t v = (threadIdx.x >= (unsigned)off) ? scan[threadIdx.x - off] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const uint32_t digitStart = scan[threadIdx.x] - myTotal;  // keys with a smaller digit, whole array
   const int base = blockIdx.x * RS_TILE + wave * (64 * RS_ITEMS);
   const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
@@ -97,7 +114,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __r
   __syncthreads();
   {
     const int dgt = threadIdx.x;  // one thread per digit
-    uint32_t run = blockHist[(size_t)dgt * numBlocks + blockIdx.x];
+    uint32_t run = digitStart + blockHist[(size_t)dgt * numBlocks + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < 4; w++) { digitBase[w][dgt] = run; run += waveCount[w][dgt]; }
   }
@@ -118,9 +135,10 @@ int sphk_sort(sph_solver* s) {
   const int nb = s->sortBlocks;
   for (int shift = 0; shift < s->sortBits; shift += 8) {
     hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.N, shift, s->blockHist, nb);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s->stream, s->blockHist, 256 * nb);
+    uint32_t* digitTotal = s->blockHist + (size_t)256 * nb;
+    hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(SPH_BLOCK), 0, s->stream, s->blockHist, nb, digitTotal);
     hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.vals, d.keysAlt, d.valsAlt,
-                       d.N, shift, s->blockHist, nb);
+                       d.N, shift, s->blockHist, nb, digitTotal);
     uint32_t* t = d.keys; d.keys = d.keysAlt; d.keysAlt = t;
     t = d.vals; d.vals = d.valsAlt; d.valsAlt = t;
   }
