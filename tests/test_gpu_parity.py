@@ -254,3 +254,22 @@ def test_stage_timing_reports_every_stage():
     t = hip.stage_times()
     assert t["density"][1] == 3 and t["predict_density"][1] == 9 and t["find_neighbors"][1] == 3
     assert all(ms >= 0 for ms, _ in t.values())
+
+
+def test_cpp_driver_matches_reference_fixture(tmp_path):
+    """host/sphmi_run.cpp: the owOpenCLSolver-compatible C++ facade driven like owPhysicsFluidSimulator, on config #1
+    text files (written here from the committed fixture), staged and fused, against the reference's positions."""
+    import subprocess
+    z = np.load(os.path.join(scenes.GOLDEN, "config1.npz"))
+    sc = scenes.config1()
+    pf, vf = tmp_path / "position.txt", tmp_path / "velocity.txt"
+    np.savetxt(pf, sc["position"], fmt="%.9e", delimiter="\t")
+    np.savetxt(vf, sc["velocity"], fmt="%.9e", delimiter="\t")
+    exe = os.path.join(scenes.PKG, "sphmi_run")
+    for extra in (["--staged"], []):
+        out = tmp_path / "pos.bin"
+        r = subprocess.run([exe, "--position", str(pf), "--velocity", str(vf), "--steps", "10", "--quiet", "--out", str(out)]
+                           + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        pos = np.fromfile(out, np.float32).reshape(-1, 4)
+        assert scenes.bits_equal(pos[z["sample_ids"]], z["position_sample_9"])
