@@ -42,6 +42,36 @@ static int dev_alloc(T** p, size_t count) {
 
 static int bit_length(uint32_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
+// Radial-histogram bin of a squared distance exactly as findNeighbors computes it (sphFluid.cl:159-160):
+// (int)(sqrt(d2) * radius_segments / h), float arithmetic, IEEE sqrt and divide (this file is built with -ffp-contract=off).
+static int radial_bin(float d2, float h) {
+  volatile float dist = sqrtf(d2);
+  volatile float scaled = dist * (float)SPH_RSEG;
+  volatile float q = scaled / h;
+  return (int)q;
+}
+static float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+// binU[j], j = 0..29: the smallest float U such that "d2 < U" <=> "d2 <= h*h and radial_bin(d2) <= j". radial_bin is
+// monotone in d2 (sqrt, multiply and divide round monotonically), so T[b] = min{ d2 : radial_bin(d2) >= b } is found by
+// bisection over the float bit patterns; U[j] = min(T[j+1], nextafter(h*h)).
+static void compute_bin_thresholds(float h, float* U) {
+  volatile float h2v = h * h;
+  const float h2 = h2v;
+  const uint32_t h2next = float_to_bits(h2) + 1u;
+  const uint32_t top = float_to_bits(16.0f * h2);
+  for (int j = 0; j < SPH_RSEG; j++) {
+    uint32_t lo = 0u, hi = top;  // smallest bit pattern with radial_bin >= j+1
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2u;
+      if (radial_bin(bits_to_float(mid), h) >= j + 1) hi = mid; else lo = mid + 1u;
+    }
+    U[j] = bits_to_float(lo < h2next ? lo : h2next);
+  }
+  U[SPH_RSEG] = U[SPH_RSEG + 1] = bits_to_float(h2next);
+}
+
 // ---------------------------------------------------------------------------------------------- timing
 struct StageTimer {
   sph_solver* s; int stage; hipEvent_t a, b; bool on;
@@ -106,7 +136,7 @@ static void free_all(sph_solver* s) {
   SphDev& d = s->d;
   void* ptrs[] = {d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
                   d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho, d.rhoPred,
-                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, s->blockHist};
+                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
   free(s->pending);
@@ -202,6 +232,9 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
   A(s->blockHist, (size_t)256 * s->sortBlocks + 256);  // [256][sortBlocks] block histograms + 256 digit totals
   A(d.dbg, 16);
+  float* binU = nullptr;
+  A(binU, 32);
+  d.binU = binU;
   if (d.hasElastic) {
     A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);
     if (membraneData && pml && cfg->numOfMembranes > 0) { A(d.membraneData, (size_t)3 * cfg->numOfMembranes); A(d.pml, (size_t)7 * d.numElastic); }
@@ -222,6 +255,11 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
       UP(d.membraneData, membraneData, sizeof(int32_t) * 3 * (size_t)cfg->numOfMembranes);
       UP(d.pml, pml, sizeof(int32_t) * 7 * (size_t)d.numElastic);
     }
+  }
+  {
+    float U[32];
+    compute_bin_thresholds(cfg->h, U);
+    UP(binU, U, sizeof(U));
   }
 #undef UP
   // buffers the reference leaves uninitialised but that an export may read before they are written

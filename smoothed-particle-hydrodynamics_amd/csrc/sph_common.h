@@ -52,6 +52,7 @@ struct SphDev {  // what the kernels see; passed by value
   float4* elastic;
   int32_t *membraneData, *pml;
   float* muscle;
+  const float* binU;  // 32 floats: d^2 < binU[j] <=> the candidate is counted in radial-histogram bins 0..j (sph_api.hip)
   uint32_t* dbg;  // 16 diagnostic counters (neighbour-search fallbacks etc.), zeroed by sph_reset_stage_times
 };
 

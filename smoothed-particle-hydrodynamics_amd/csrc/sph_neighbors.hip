@@ -127,17 +127,23 @@ __device__ __forceinline__ void find_neighbors_slow(const SphDev& d, int id, uin
   }
 }
 
-#define FN_PART 256         // particles per workgroup
-#define FN_THREADS 512      // two lanes per particle: 8 waves = 2 per SIMD with one workgroup per CU
-#define FN_CAND_CAP 5632    // staged candidates per workgroup (float4: 88 KB)
-#define FN_CAND_PAD 4       // the 4-wide walk may read (never use) up to 3 slots past a cell
+#ifndef FN_PART
+#define FN_PART 128         // particles per workgroup (A/B on config #2: 128 -> 0.89 ms, 256 -> 0.96 ms)
+#endif
+#define FN_THREADS (2 * FN_PART)  // two lanes per particle
+#ifndef FN_CAND_CAP
+#define FN_CAND_CAP 4096    // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
+#endif
+#define FN_CAND_PAD 8       // the aligned, prefetching 4-wide walk reads (never uses) up to 7 slots past a cell
 #define FN_LIST_CAP 48      // compaction list entries per lane (u16: 48 KB per workgroup)
-#define FN_HIST_WORDS 15    // 30 bins as packed u16 pairs, one histogram per particle (15 KB per workgroup)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FnShared {
-  float4 cand[FN_CAND_CAP + FN_CAND_PAD];         // x, y, z, sorted index (int bits)
+  float x[FN_CAND_CAP + FN_CAND_PAD], y[FN_CAND_CAP + FN_CAND_PAD], z[FN_CAND_CAP + FN_CAND_PAD];  // staged candidates
   uint16_t list[FN_LIST_CAP][FN_THREADS];         // [entry][lane] LDS slots of the filter hits, traversal order
-  uint32_t hist[FN_HIST_WORDS][FN_PART];          // [bin pair][particle]
+  float binU[32];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j (see SphDev::binU)
   int rowLo[9], rowHi[9], rowBase[9];             // staged runs: sorted-index range and first LDS slot
 };
 
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     if (a <= b) { lo = (int)d.cellStart[a]; hi = (int)d.cellStart[b + 1]; }
     sh.rowLo[tid] = lo; sh.rowHi[tid] = hi;
   }
+  if (tid >= 64 && tid < 96) sh.binU[tid - 64] = d.binU[tid - 64];
   __syncthreads();
   if (tid == 0) {
     int base = 0;
@@ -186,19 +193,19 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   for (int r = 0; r < 9; r++) {
     const int lo = sh.rowLo[r], n = sh.rowHi[r] - lo, base = sh.rowBase[r];
     for (int t = tid; t < n; t += FN_THREADS) {
-      float4 q = d.sortedPos[lo + t];
-      q.w = __int_as_float(lo + t);
-      sh.cand[base + t] = q;
+      const float4 q = d.sortedPos[lo + t];
+      sh.x[base + t] = q.x; sh.y[base + t] = q.y; sh.z[base + t] = q.z;
     }
   }
   __syncthreads();
-
   if (experiment == 1) return;  // timing experiment: staging only
+
   float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
   bool slow = false;
-  int ldsLo[4], num[4];
+  int ldsLo[4], num[4], absDelta[4];  // absDelta: sorted index = LDS slot + absDelta
+  int selfSlot = -1;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { num[i] = 0; ldsLo[i] = 0; }
+  for (int i = 0; i < 4; i++) { num[i] = 0; ldsLo[i] = 0; absDelta[i] = 0; }
   if (alive) {
     me = d.sortedPos[id];
     CellSet cs;
@@ -212,7 +219,8 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
         if (r >= 0 && cs.lo[k] >= sh.rowLo[r] && cs.hi[k] <= sh.rowHi[r]) base = sh.rowBase[r] + (cs.lo[k] - sh.rowLo[r]);
         else slow = true;  // a non-empty cell of this particle is not in LDS (both lanes of the pair see this)
       }
-      if ((k & 1) == half) { num[k >> 1] = n; ldsLo[k >> 1] = base; }
+      if ((k & 1) == half) { num[k >> 1] = n; ldsLo[k >> 1] = base; absDelta[k >> 1] = cs.lo[k] - base; }
+      if (k == 0 && half == 0) selfSlot = base + (id - cs.lo[0]);  // the particle itself sits in its own cell
     }
   }
   if (slow) {
@@ -222,33 +230,59 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
 
   // ---- 1. single walk with the cheap filter; r_max covers pass 0 (h) and every possible pass-1 radius (<= 31h/30).
-  // Four candidates per trip: the four LDS reads are issued together so their latency overlaps.
+  // Four candidates per trip from 16-byte-aligned SoA reads (the walk starts at the aligned slot at or before the cell and
+  // masks what lies outside [0, n)); the arithmetic is packed f32 (v_pk_*), IEEE per component, same order as the reference.
   const float rA = d.h, rB = (float)(SPH_RSEG + 1) * d.h / (float)SPH_RSEG;
   const float r2max = fmaxf(rA * rA, rB * rB);
-  const int selfId = (half == 0) ? id : -1;  // only cell k = 0 (lane 0 of the pair, first cell) can hold the particle itself
   int cnt = 0;
   int segEnd[4];
-#define FN_VISIT(o, u)                                                                        \
-  {                                                                                           \
-    const float ex = me.x - (o).x, ey = me.y - (o).y, ez = me.z - (o).z;                      \
-    const float d2 = ex * ex + ey * ey + ez * ez;                                             \
-    bool hit = (d2 <= r2max) && (t + (u) < n);                                                \
-    if (i == 0) hit = hit && (__float_as_int((o).w) != selfId);                               \
-    if (hit) {                                                                                \
-      if (cnt < FN_LIST_CAP) sh.list[cnt][tid] = (uint16_t)(base + t + (u));                  \
-      cnt++;                                                                                  \
-    }                                                                                         \
+  const f32x2 mx = {me.x, me.x}, my = {me.y, me.y}, mz = {me.z, me.z};
+  // one aligned quad of candidates; CHECKED quads (first / last of a cell) also test that the slot lies inside the cell
+#define FN_LOAD(a, X, Y, Z)                                                                     \
+  const f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);                                    \
+  const f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);                                    \
+  const f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
+#define FN_TEST(a, X, Y, Z, CHECKED)                                                            \
+  {                                                                                             \
+    const f32x2 ex0 = mx - X.xy, ex1 = mx - X.zw, ey0 = my - Y.xy, ey1 = my - Y.zw;             \
+    const f32x2 ez0 = mz - Z.xy, ez1 = mz - Z.zw;                                               \
+    const f32x2 q0 = ex0 * ex0 + ey0 * ey0 + ez0 * ez0, q1 = ex1 * ex1 + ey1 * ey1 + ez1 * ez1; \
+    const float d2[4] = {q0.x, q0.y, q1.x, q1.y};                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                             \
+      bool hit = d2[u] <= r2max;                                                                \
+      if (CHECKED) hit = hit && ((unsigned)((a) + u - cellLo) < (unsigned)n);                   \
+      if (i == 0) hit = hit && ((a) + u != selfSlot);                                           \
+      if (hit) sh.list[min(cnt, FN_LIST_CAP - 1)][tid] = (uint16_t)((a) + u);                   \
+      cnt += hit ? 1 : 0;                                                                       \
+    }                                                                                           \
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int n = num[i], base = ldsLo[i];
-    for (int t = 0; t < n; t += 4) {
-      const float4 o0 = sh.cand[base + t], o1 = sh.cand[base + t + 1], o2 = sh.cand[base + t + 2], o3 = sh.cand[base + t + 3];
-      FN_VISIT(o0, 0) FN_VISIT(o1, 1) FN_VISIT(o2, 2) FN_VISIT(o3, 3)
+    const int n = num[i], cellLo = ldsLo[i], cellHi = cellLo + n;
+    if (n > 0) {
+      int a = cellLo & ~3;  // aligned slot at or before the cell
+      { FN_LOAD(a, X, Y, Z) FN_TEST(a, X, Y, Z, true) }
+      a += 4;
+      if (a + 4 <= cellHi) {
+        // interior quads lie wholly inside the cell; the next quad's three LDS reads are issued before the current
+        // quad is tested (software pipelining: the wave has only one partner on its SIMD to hide LDS latency)
+        f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);
+        f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);
+        f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
+        for (; a + 8 <= cellHi; a += 4) {
+          FN_LOAD(a + 4, Xn, Yn, Zn)
+          FN_TEST(a, X, Y, Z, false)
+          X = Xn; Y = Yn; Z = Zn;
+        }
+        FN_TEST(a, X, Y, Z, false)
+        a += 4;
+      }
+      if (a < cellHi) { FN_LOAD(a, X, Y, Z) FN_TEST(a, X, Y, Z, true) }
     }
     segEnd[i] = cnt;
   }
-#undef FN_VISIT
+#undef FN_LOAD
+#undef FN_TEST
   if (experiment == 2) { if (cnt == 12345) d.dbg[15] = 1; return; }  // timing experiment: staging + walk
   bool over = cnt > FN_LIST_CAP;
   over = over || (__shfl_xor((int)over, 1) != 0);
@@ -259,67 +293,62 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     for (int i = 0; i < 4; i++) segEnd[i] = 0;
   }
 
-  // ---- 2. replay of the reference's two passes over the short lists, entirely in registers.
-  // The list (<= 48 LDS slots per lane) is expanded once into d2[] / idx[] with static indices: all list reads, then all
-  // candidate reads are in flight together, and pass 0 (histogram), the threshold and pass 1 (selection + slot
-  // assignment) never touch LDS for candidate data again.
+  // ---- 2. replay of the reference's two passes over the short lists, entirely in registers: the list (<= 48 LDS slots
+  // per lane) is expanded once into d2v[] / slotv[] with static indices, 8 entries at a time with a wave-uniform skip.
   const int total = segEnd[3];
   float d2v[FN_LIST_CAP];
-  int idxv[FN_LIST_CAP];
+  int slotv[FN_LIST_CAP];
 #pragma unroll
-  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 16) {
-    if (__any(c0 < total)) {  // wave-uniform skip of empty 16-entry chunks
-      uint32_t slot[16];
+  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+    if (__any(c0 < total)) {
 #pragma unroll
-      for (int u = 0; u < 16; u++) slot[u] = min((uint32_t)sh.list[c0 + u][tid], (uint32_t)(FN_CAND_CAP + FN_CAND_PAD - 1));
+      for (int u = 0; u < 8; u++) slotv[c0 + u] = min((int)sh.list[c0 + u][tid], FN_CAND_CAP + FN_CAND_PAD - 1);
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const float4 o = sh.cand[slot[u]];
-        const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-        d2v[c0 + u] = ex * ex + ey * ey + ez * ez;
-        idxv[c0 + u] = __float_as_int(o.w);
+      for (int u = 0; u < 8; u++) {
+        const int sl = slotv[c0 + u];
+        const float ex = me.x - sh.x[sl], ey = me.y - sh.y[sl], ez = me.z - sh.z[sl];
+        const float v = ex * ex + ey * ey + ez * ez;
+        d2v[c0 + u] = (c0 + u < total) ? v : __builtin_inff();  // +inf never passes a `<` / `<=` test below
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < 16; u++) { d2v[c0 + u] = 0.f; idxv[c0 + u] = -1; }
+      for (int u = 0; u < 8; u++) { d2v[c0 + u] = __builtin_inff(); slotv[c0 + u] = 0; }
     }
   }
-  // ---- 2a. pass 0: per-particle 30-bin histogram of the hits with d^2 <= h^2 (sphFluid.cl:157-161)
-  for (int w = half; w < FN_HIST_WORDS; w += 2) sh.hist[w][p] = 0u;
-  const float h2 = d.h * d.h;
+  // ---- 2a. pass 0 + threshold (sphFluid.cl:157-161,310-323) without building the histogram: C(j) = number of hits in
+  // bins 0..j = number of hits with d^2 < U[j] (U precomputed exactly on the host). The reference's loop stops at
+  // j* = min{ j : C(j) >= 32 } with jb = j* if C(j*) == 32, j* - 1 if it overshoots, and jb = 30 if no such j exists.
+  int lo = 0, hi = SPH_RSEG, cAtHi = 0;
+#pragma unroll 1
+  for (int it = 0; it < 5; it++) {
+    const int mid = (lo + hi) >> 1;  // lo == hi on converged lanes: harmless re-evaluation
+    const float U = sh.binU[min(mid, SPH_RSEG - 1)];
+    int c = 0;
 #pragma unroll
-  for (int e = 0; e < FN_LIST_CAP; e++) {
-    if (e < total && d2v[e] <= h2) {
-      const float dist = sqrtf(d2v[e]);
-      const int bin = (int)(dist * (float)SPH_RSEG / d.h);
-      if (bin < SPH_RSEG) atomicAdd(&sh.hist[bin >> 1][p], 1u << ((bin & 1) << 4));
+    for (int e = 0; e < FN_LIST_CAP; e++) c += (d2v[e] < U) ? 1 : 0;
+    c += __shfl_xor(c, 1);
+    if (lo < hi) {
+      if (c >= SPH_MAXN) { hi = mid; cAtHi = c; } else lo = mid + 1;
     }
   }
-  // ---- threshold (sphFluid.cl:310-323); both lanes of a pair read the same histogram (same wave: LDS ops are ordered)
-  int jb = 0, sum = 0;
-  while (jb < SPH_RSEG) {
-    sum += (int)((sh.hist[jb >> 1][p] >> ((jb & 1) << 4)) & 0xffffu);
-    if (sum == SPH_MAXN) break;
-    if (sum > SPH_MAXN) { jb--; break; }
-    jb++;
-  }
+  const int jb = (lo >= SPH_RSEG) ? SPH_RSEG : ((cAtHi == SPH_MAXN) ? lo : lo - 1);
   const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
   const float r2 = r_thr * r_thr;
-  if (experiment == 3) { if (r2 == 12345.f) d.dbg[15] = 1; return; }  // timing experiment: + histogram pass
+  if (experiment == 3) { if (r2 == 12345.f) d.dbg[15] = 1; return; }  // timing experiment: + threshold search
 
-  // ---- 2b. pass 1: hits with d^2 <= r_thr^2. Count them per cell, swap the four counts inside the pair, then write
-  // every hit at (hits in earlier cells of the merged order) + (rank inside its cell); slots >= 32 are dropped, which is
-  // what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
-  int mine[4] = {0, 0, 0, 0};
+  // ---- 2b. pass 1: hits with d^2 <= r_thr^2 as a bit mask; per-cell counts by popcount; swap the four counts inside the
+  // pair; every hit goes to (hits in earlier cells of the merged order) + (rank inside its cell). Slots >= 32 are
+  // dropped, which is what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
+  unsigned long long acc = 0ull;
 #pragma unroll
-  for (int e = 0; e < FN_LIST_CAP; e++) {
-    const int acc = (e < total && d2v[e] <= r2) ? 1 : 0;
-    mine[0] += (e < segEnd[0]) ? acc : 0;
-    mine[1] += (e >= segEnd[0] && e < segEnd[1]) ? acc : 0;
-    mine[2] += (e >= segEnd[1] && e < segEnd[2]) ? acc : 0;
-    mine[3] += (e >= segEnd[2]) ? acc : 0;
-  }
-  int theirs[4];
+  for (int e = 0; e < FN_LIST_CAP; e++) acc |= (d2v[e] <= r2) ? (1ull << e) : 0ull;
+  unsigned long long below[4];  // bits of the entries before the end of cell i
+#pragma unroll
+  for (int i = 0; i < 4; i++) below[i] = (segEnd[i] >= 64) ? ~0ull : ((1ull << segEnd[i]) - 1ull);
+  int mine[4], theirs[4];
+  mine[0] = __popcll(acc & below[0]);
+#pragma unroll
+  for (int i = 1; i < 4; i++) mine[i] = __popcll(acc & below[i] & ~below[i - 1]);
 #pragma unroll
   for (int i = 0; i < 4; i++) theirs[i] = __shfl_xor(mine[i], 1);
   if (alive && !slow) {
@@ -330,23 +359,28 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
       run += mine[i] + theirs[i];
     }
     if (experiment == 5) { if (run == 12345) d.dbg[15] = 1; return; }  // timing experiment: no write loop
-    // position of entry e = start of its cell + hits before it inside the cell
-    int pos = start[0];
+    // walk the entries in list order with a running (cell start, index delta, rank inside the cell)
+    int curStart = start[0], curDelta = absDelta[0], rank = 0;
+    int32_t* const idBase = d.nbrId + (((size_t)(id >> 6) * 8 * 64 + (size_t)(id & 63)) << 2);
+    float* const distBase = d.nbrDist + (((size_t)(id >> 6) * 8 * 64 + (size_t)(id & 63)) << 2);
 #pragma unroll
-    for (int e = 0; e < FN_LIST_CAP; e++) {
-      if (e == segEnd[0]) pos = start[1];  // (segments may be empty: later assignments win, in order)
-      if (e == segEnd[1]) pos = start[2];
-      if (e == segEnd[2]) pos = start[3];
-      if (e < total && d2v[e] <= r2) {
-        if (pos < SPH_MAXN) {
-          const size_t idx = nbr_index(id, pos);
-          if (experiment == 4) { if (sqrtf(d2v[e]) * d.simScale == 12345.f) d.dbg[15] = idxv[e]; }
-          else {
-            d.nbrId[idx] = idxv[e];
-            d.nbrDist[idx] = sqrtf(d2v[e]) * d.simScale;
+    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+      if (!__any(c0 < total)) continue;  // wave-uniform skip of empty chunks
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = c0 + u;
+        if (e == segEnd[0]) { curStart = start[1]; curDelta = absDelta[1]; rank = 0; }  // (empty cells cascade in order)
+        if (e == segEnd[1]) { curStart = start[2]; curDelta = absDelta[2]; rank = 0; }
+        if (e == segEnd[2]) { curStart = start[3]; curDelta = absDelta[3]; rank = 0; }
+        if ((acc >> e) & 1ull) {
+          const int pos = curStart + rank;
+          rank++;
+          if (pos < SPH_MAXN) {
+            const int off = ((pos >> 2) << 8) + (pos & 3);  // tiled map: group stride 64 lanes * 4 slots
+            idBase[off] = slotv[e] + curDelta;
+            distBase[off] = sqrtf(d2v[e]) * d.simScale;
           }
         }
-        pos++;
       }
     }
     for (int k = min(run, SPH_MAXN) + half; k < SPH_MAXN; k += 2) {  // K1 folded in: unused slots = (-1, -1)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libsphmi.so")
+LIB_PATH = os.environ.get("SPHMI_LIB", os.path.join(_PKG, "libsphmi.so"))  # SPHMI_LIB: A/B builds of the same ABI
 HOST_LIB_PATH = os.path.join(_PKG, "libsphmi_host.so")
 
 ABI_VERSION = 1
