@@ -187,7 +187,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   density *= d.massWpoly6;
   const float rp = (float)density;
   d.rhoPred[id] = rp;
-  if (FUSE_CORRECT) d.pressure[id] = corrected_pressure(d, d.pressure[id], rp);
+  if (FUSE_CORRECT) {
+    const float pnew = corrected_pressure(d, d.pressure[id], rp);
+    d.pressure[id] = pnew;
+    const float4 x = d.sortedPos[id];
+    d.posPress[id] = make_float4(x.x, x.y, x.z, pnew);  // packed for the neighbour gathers of the pressure-force kernel
+  }
 }
 
 int sphk_predict_density(sph_solver* s, bool fuseCorrect) {
@@ -201,7 +206,10 @@ int sphk_predict_density(sph_solver* s, bool fuseCorrect) {
 __global__ __launch_bounds__(SPH_BLOCK) void k_correct_pressure(SphDev d) {
   const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (id >= d.N) return;
-  d.pressure[id] = corrected_pressure(d, d.pressure[id], d.rhoPred[id]);
+  const float pnew = corrected_pressure(d, d.pressure[id], d.rhoPred[id]);
+  d.pressure[id] = pnew;
+  const float4 x = d.sortedPos[id];
+  d.posPress[id] = make_float4(x.x, x.y, x.z, pnew);
 }
 
 int sphk_correct_pressure(sph_solver* s) {
@@ -315,9 +323,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
       const int jd = jj[k];
       const float r = rr[k];
       if (jd != -1 && r < d.hs) {
-        const float4 xj = d.sortedPos[jd];
+        const float4 xj = d.posPress[jd];  // (x, y, z, pressure_j)
         const float rpj = d.rhoPred[jd];
-        float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + d.pressure[jd]) / rpj;
+        float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj.w) / rpj;
         const float vx = (xi.x - xj.x) * d.simScale, vy = (xi.y - xj.y) * d.simScale, vz = (xi.z - xj.z) * d.simScale;
         if ((double)r < d.closeR) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj;
         rx += value * vx / r;
