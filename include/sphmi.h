@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SPHMI_ABI_VERSION 1
+#define SPHMI_ABI_VERSION 2
 #define SPH_MAX_NEIGHBOR_COUNT 32 /* owOpenCLConstant.h:4 */
 #define SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE 7 /* owOpenCLConstant.h:6 */
 #define SPH_LIQUID_PARTICLE 1   /* owOpenCLConstant.h:8-10 */
@@ -46,6 +46,8 @@ typedef enum sph_status {
 typedef struct sph_config {
   int32_t abi_version;      /* SPHMI_ABI_VERSION */
   int32_t particleCount;    /* PARTICLE_COUNT */
+  int32_t capacity;         /* buffers are sized for this many particles (slab decomposition: the count varies per step);
+                               0 = particleCount */
   int32_t gridCellsX, gridCellsY, gridCellsZ, gridCellCount; /* owOpenCLSolver.cpp:14-17 */
   uint32_t cellIdMask;      /* 0xffff = reference behaviour (sphFluid.cl:229,377); 0xffffffff = wide */
   float h, hashGridCellSize, hashGridCellSizeInv, simulationScale, simulationScaleInv; /* owPhysicsConstant.h:19-24 */
@@ -130,6 +132,35 @@ typedef enum sph_stage {
 int sph_set_stage_timing(sph_solver* s, int enable);
 int sph_get_stage_times(sph_solver* s, double* ms_total, int64_t* launches, int n); /* n = SPH_ST_COUNT */
 int sph_reset_stage_times(sph_solver* s);
+
+/* ---- Spatial decomposition (no reference counterpart: the reference is single-device) -----------------
+ * The global box is cut into z-slabs of whole cell layers, one solver (one GPU, one process) per slab. A solver holds the
+ * particles of its own layers [layerLo, layerHi) plus `ghostLayers` layers on each side and advances ALL of them with the
+ * ordinary sph_step(); only the particles it owned when the set was last rebuilt are authoritative afterwards. Once per
+ * step the authoritative particles near a cut are sent to the neighbouring solver (sph_slab_pack -> the caller's
+ * RCCL send/recv -> sph_slab_rebuild), which replaces its whole ghost zone with them. ghostLayers = 4 cell layers (8h)
+ * cover the 6 neighbour hops (6 x 31h/30) that one PCISPH step propagates information, so owned particles get bit-identical
+ * results to a single-solver run; the local arrays are kept sorted by global id so that the within-cell order (ascending
+ * orig id) is the global one. Requires cellIdMask = 0xffffffff.
+ * Message = n records of 9 words: position (x,y,z,type), velocity (vx,vy,vz,w), global id. All pointers below are DEVICE
+ * pointers on the solver's device. */
+typedef struct sph_slab {
+  int32_t layerLo, layerHi;   /* owned cell layers along z: cz = (int)(z * hashGridCellSizeInv) */
+  int32_t ghostLayers;        /* W */
+  int32_t hasLower, hasUpper; /* a neighbouring slab exists below / above */
+  int32_t globalIdBits;       /* bit length of the largest global id */
+} sph_slab;
+#define SPH_SLAB_RECORD_WORDS 9
+int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t* globalIds /* host, particleCount entries */);
+/* counts[0] = authoritative particles kept, counts[1] / counts[2] = records written to msgDown / msgUp (each has room for
+ * `capRecords`). Blocking (the counts come back to the host). */
+int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t capRecords, int32_t counts[3]);
+/* New local set = kept + nDown records received from below + nUp from above, sorted by global id. */
+int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp);
+int sph_particle_count(sph_solver* s);
+/* Blocking read of the local set in its current order: positions, velocities (4 floats each), global ids and the
+ * ownership flag (1 = in the owned layers when the set was last rebuilt); arrays sized sph_particle_count(). */
+int sph_slab_read(sph_solver* s, float* position4, float* velocity4, uint32_t* globalIds, uint32_t* owned);
 
 const char* sph_last_error(void);
 int sph_abi_version(void);

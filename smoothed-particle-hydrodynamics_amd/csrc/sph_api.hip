@@ -136,7 +136,8 @@ static void free_all(sph_solver* s) {
   SphDev& d = s->d;
   void* ptrs[] = {d.posPress, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
                   d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho, d.rhoPred,
-                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, s->blockHist};
+                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
+                  s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
   free(s->pending);
@@ -160,7 +161,8 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   *out = nullptr;
   if (cfg->abi_version != SPHMI_ABI_VERSION) { sph_set_error("sph_config.abi_version %d != %d", cfg->abi_version, SPHMI_ABI_VERSION); return SPH_ERR_INVALID; }
   const int N = cfg->particleCount;
-  if (N <= 0 || (long long)N * 32 >= 0x7fffffffLL * 4LL) { sph_set_error("particleCount %d out of range", N); return SPH_ERR_INVALID; }
+  const int cap = cfg->capacity > 0 ? cfg->capacity : N;
+  if (N <= 0 || cap < N || (long long)cap * 32 >= 0x7fffffffLL * 4LL) { sph_set_error("particleCount %d / capacity %d out of range", N, cap); return SPH_ERR_INVALID; }
   if (cfg->gridCellsX <= 0 || cfg->gridCellsY <= 0 || cfg->gridCellsZ <= 0 ||
       (long long)cfg->gridCellsX * cfg->gridCellsY * cfg->gridCellsZ != (long long)cfg->gridCellCount) {
     sph_set_error("gridCellCount does not equal gridCellsX*gridCellsY*gridCellsZ");
@@ -217,20 +219,22 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   d.numElastic = cfg->numOfElasticP; d.elasticOffset = cfg->elasticOffset; d.muscleCount = cfg->muscleCount;
   d.numMembranes = cfg->numOfMembranes; d.hasElastic = cfg->numOfElasticP > 0;
 
-  s->numTiles = (N + SPH_TILE - 1) / SPH_TILE;
+  s->capacity = cap;
+  s->capTiles = (cap + SPH_TILE - 1) / SPH_TILE;
   s->sortBits = (cfg->cellIdMask == 0xffffu) ? 16 : bit_length((uint32_t)(d.G > 0 ? d.G - 1 : 0));
   if (s->sortBits < 1) s->sortBits = 1;
-  s->sortBlocks = (N + (SPH_BLOCK * 16) - 1) / (SPH_BLOCK * 16);
+  s->maxSortBlocks = (cap + (SPH_BLOCK * 16) - 1) / (SPH_BLOCK * 16);
 
   int rc = SPH_OK;
-  const size_t n = (size_t)N, G1 = (size_t)d.G + 1, mapN = (size_t)s->numTiles * 64 * 32;
+  const size_t n = (size_t)cap, nUp = (size_t)N, G1 = (size_t)d.G + 1, mapN = (size_t)s->capTiles * 64 * 32;
 #define A(ptr, count) if (rc == SPH_OK) rc = dev_alloc(&(ptr), (count))
   A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.posPress, n);
   A(d.keys, n); A(d.vals, n); A(d.keysAlt, n); A(d.valsAlt, n); A(d.backIndex, n);
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
   A(d.nbrId, mapN); A(d.nbrDist, mapN);
   A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
-  A(s->blockHist, (size_t)256 * s->sortBlocks + 256);  // [256][sortBlocks] block histograms + 256 digit totals
+  A(s->blockHist, (size_t)256 * s->maxSortBlocks + 256);  // [256][maxSortBlocks] block histograms + 256 digit totals
+  A(d.gid, n); A(d.owned, n); A(s->slabCounts, 4);
   A(d.dbg, 16);
   float* binU = nullptr;
   A(binU, 32);
@@ -244,8 +248,8 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
 
 #define UP(dst, src, bytes) do { hipError_t e_ = hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, s->stream); \
     if (e_ != hipSuccess) { sph_set_error("upload failed: %s", hipGetErrorString(e_)); free_all(s); delete s; return SPH_ERR_HIP; } } while (0)
-  UP(d.posOrig, position, sizeof(float4) * n);
-  UP(d.velOrig, velocity, sizeof(float4) * n);
+  UP(d.posOrig, position, sizeof(float4) * nUp);
+  UP(d.velOrig, velocity, sizeof(float4) * nUp);
   if (d.hasElastic) {
     UP(d.elastic, elastic, sizeof(float4) * 32 * (size_t)d.numElastic);
     // quirk #18: the reference never uploads the signal before step 0 (zeros in practice)
@@ -488,6 +492,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   if (!name) return SPH_ERR_INVALID;
   const SphDev& d = s->d;
   const size_t n = (size_t)d.N, G1 = (size_t)d.G + 1;
+  const int numTiles = (d.N + SPH_TILE - 1) / SPH_TILE;
   size_t need = 0;
   enum { B_POS, B_VEL, B_SPOS, B_SVEL, B_ACC, B_NMAP, B_NIDS, B_PI, B_PIB, B_GCI, B_GCIF, B_P, B_RHO, B_DBG } which;
   if (!strcmp(name, "position")) { which = B_POS; need = sizeof(float4) * 2 * n; }
@@ -544,7 +549,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
       break;
     case B_NMAP:
     case B_NIDS: {
-      const size_t mapN = (size_t)s->numTiles * 64 * 32;
+      const size_t mapN = (size_t)numTiles * 64 * 32;
       std::vector<int32_t> ids(mapN);
       std::vector<float> dist(mapN);
       rc = d2h(s, ids.data(), d.nbrId, sizeof(int32_t) * mapN);
@@ -568,5 +573,63 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
       if (rc == SPH_OK) rc = d2h(s, o + sizeof(float) * n, d.rhoPred, sizeof(float) * n);
       break;
   }
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- slab decomposition
+extern "C" int sph_particle_count(sph_solver* s) { return s ? s->d.N : SPH_ERR_INVALID; }
+
+extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t* globalIds) {
+  ENTER(s);
+  if (!slab || !globalIds) { sph_set_error("sph_slab_init: null argument"); return SPH_ERR_INVALID; }
+  if (s->cfg.cellIdMask != 0xffffffffu) { sph_set_error("slab decomposition needs wide cell ids (cellIdMask = 0xffffffff)"); return SPH_ERR_INVALID; }
+  if (s->d.hasElastic) { sph_set_error("slab decomposition supports pure-liquid scenes only"); return SPH_ERR_INVALID; }
+  if (slab->layerLo >= slab->layerHi || slab->ghostLayers < 1 || slab->globalIdBits < 1 || slab->globalIdBits > 32) { sph_set_error("bad sph_slab"); return SPH_ERR_INVALID; }
+  s->slab = *slab; s->hasSlab = true;
+  SPH_HIP(hipMemcpyAsync(s->d.gid, globalIds, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyHostToDevice, s->stream));
+  // ownership flags from the initial positions: reuse the rebuild path with nothing received
+  SPH_HIP(hipMemcpyAsync(s->d.sortedPos, s->d.posOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
+  SPH_HIP(hipMemcpyAsync(s->d.sortedVel, s->d.velOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
+  SPH_HIP(hipMemcpyAsync(s->d.keys, s->d.gid, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
+  int rc = sphk_slab_rebuild(s, nullptr, 0, nullptr, 0, s->d.N);
+  if (rc != SPH_OK) return rc;
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  return SPH_OK;
+}
+
+extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t capRecords, int32_t counts[3]) {
+  ENTER(s);
+  if (!s->hasSlab || !counts || capRecords < 0 || ((s->slab.hasLower && !msgDown) || (s->slab.hasUpper && !msgUp))) {
+    sph_set_error("sph_slab_pack: slab not initialised or null message buffer"); return SPH_ERR_INVALID; }
+  int rc = sphk_slab_pack(s, (uint32_t*)msgDown, (uint32_t*)msgUp, capRecords);
+  if (rc != SPH_OK) return rc;
+  uint32_t h[4];
+  SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  counts[0] = (int32_t)h[0]; counts[1] = (int32_t)h[1]; counts[2] = (int32_t)h[2];
+  if ((int)h[1] > capRecords || (int)h[2] > capRecords) { sph_set_error("halo message overflow: %u / %u records, room for %d", h[1], h[2], capRecords); return SPH_ERR_SIZE; }
+  return SPH_OK;
+}
+
+extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp) {
+  ENTER(s);
+  if (!s->hasSlab || nDown < 0 || nUp < 0 || (nDown && !recvDown) || (nUp && !recvUp)) { sph_set_error("sph_slab_rebuild: bad arguments"); return SPH_ERR_INVALID; }
+  uint32_t h[4];
+  SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  const long long total = (long long)h[0] + nDown + nUp;
+  if (total > s->capacity || total <= 0) { sph_set_error("slab holds %lld particles after the exchange, capacity %d", total, s->capacity); return SPH_ERR_SIZE; }
+  return sphk_slab_rebuild(s, (const uint32_t*)recvDown, nDown, (const uint32_t*)recvUp, nUp, (int)h[0]);
+}
+
+extern "C" int sph_slab_read(sph_solver* s, float* position4, float* velocity4, uint32_t* globalIds, uint32_t* owned) {
+  ENTER(s);
+  if (!s->hasSlab) { sph_set_error("slab not initialised"); return SPH_ERR_INVALID; }
+  const size_t n = (size_t)s->d.N;
+  int rc = SPH_OK;
+  if (position4) rc = d2h(s, position4, s->d.posOrig, sizeof(float4) * n);
+  if (rc == SPH_OK && velocity4) rc = d2h(s, velocity4, s->d.velOrig, sizeof(float4) * n);
+  if (rc == SPH_OK && globalIds) rc = d2h(s, globalIds, s->d.gid, sizeof(uint32_t) * n);
+  if (rc == SPH_OK && owned) rc = d2h(s, owned, s->d.owned, sizeof(uint32_t) * n);
   return rc;
 }

@@ -47,6 +47,7 @@ struct SphDev {  // what the kernels see; passed by value
   float4* posPress;  // (sortedPos.xyz, pressure): what the pressure-force kernel gathers per neighbour, one 16-B load
   uint32_t *keys, *vals, *keysAlt, *valsAlt, *backIndex;
   uint32_t *cellStart, *cellStartRaw;
+  uint32_t *gid, *owned;  // slab decomposition: global id and ownership flag per local particle (orig order)
   int32_t* nbrId;
   float* nbrDist;
   float *rho, *rhoPred, *pressure;
@@ -63,10 +64,13 @@ struct sph_solver {
   hipStream_t stream;
   bool ownStream;
   int sortBits;              // significant bits of the sort key
-  int numTiles;              // ceil(N/64)
+  int capacity;              // particles the buffers are sized for (>= d.N)
+  int capTiles;              // ceil(capacity/64)
+  sph_slab slab; bool hasSlab;
+  uint32_t* slabCounts;      // device: kept / down / up counters
   // radix-sort workspace
-  uint32_t* blockHist;       // [256][sortBlocks]
-  int sortBlocks;
+  uint32_t* blockHist;       // [256][maxSortBlocks] block histograms + 256 digit totals
+  int maxSortBlocks;
   // stage progress for SPH_ERR_ORDER checks
   int progress;
   // stage timing
@@ -102,6 +106,7 @@ __host__ __device__ static inline size_t nbr_index(int id, int slot) {
 // sph_sort.hip
 int sphk_hash(sph_solver* s);
 int sphk_sort(sph_solver* s);
+int sphk_sort_pairs(sph_solver* s, int n, int bits);  // stable LSD sort of (keys, vals)[0..n) by the low `bits` of keys
 int sphk_sort_post(sph_solver* s);        // gather + backIndex (K3)
 int sphk_index_raw(sph_solver* s);        // K4 table with -1 for empty cells
 int sphk_index_fixed(sph_solver* s);      // H2 table (cellStart)
@@ -117,6 +122,9 @@ int sphk_predict_density(sph_solver* s, bool fuseCorrect);
 int sphk_correct_pressure(sph_solver* s);
 int sphk_pressure_force(sph_solver* s, int fuse);  // 0 none, 1 + predictPositions, 2 + integrate
 int sphk_integrate(sph_solver* s);
+// sph_slab.hip
+int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords);
+int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept);
 // sph_elastic.hip
 int sphk_elastic(sph_solver* s);
 int sphk_clear_membranes(sph_solver* s);

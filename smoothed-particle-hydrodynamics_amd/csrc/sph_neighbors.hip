@@ -30,7 +30,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_clear_neighbors(int32_t* __restri
 }
 
 int sphk_clear_neighbors(sph_solver* s) {
-  const size_t n4 = (size_t)s->numTiles * 64 * 8;
+  const size_t n4 = (size_t)((s->d.N + SPH_TILE - 1) / SPH_TILE) * 64 * 8;
   hipLaunchKernelGGL(k_clear_neighbors, dim3((unsigned)((n4 + SPH_BLOCK - 1) / SPH_BLOCK)), dim3(SPH_BLOCK), 0, s->stream,
                      s->d.nbrId, s->d.nbrDist, n4);
   SPH_HIP(hipGetLastError());

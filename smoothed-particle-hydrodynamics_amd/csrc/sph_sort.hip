@@ -130,15 +130,18 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __r
   }
 }
 
-int sphk_sort(sph_solver* s) {
+int sphk_sort(sph_solver* s) { return sphk_sort_pairs(s, s->d.N, s->sortBits); }
+
+int sphk_sort_pairs(sph_solver* s, int n, int bits) {
   SphDev& d = s->d;
-  const int nb = s->sortBlocks;
-  for (int shift = 0; shift < s->sortBits; shift += 8) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.N, shift, s->blockHist, nb);
-    uint32_t* digitTotal = s->blockHist + (size_t)256 * nb;
+  const int nb = (n + RS_TILE - 1) / RS_TILE;
+  if (nb > s->maxSortBlocks) { sph_set_error("sort of %d keys exceeds the solver's capacity", n); return SPH_ERR_SIZE; }
+  for (int shift = 0; shift < bits; shift += 8) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, n, shift, s->blockHist, nb);
+    uint32_t* digitTotal = s->blockHist + (size_t)256 * s->maxSortBlocks;
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(SPH_BLOCK), 0, s->stream, s->blockHist, nb, digitTotal);
     hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.vals, d.keysAlt, d.valsAlt,
-                       d.N, shift, s->blockHist, nb, digitTotal);
+                       n, shift, s->blockHist, nb, digitTotal);
     uint32_t* t = d.keys; d.keys = d.keysAlt; d.keysAlt = t;
     t = d.vals; d.vals = d.valsAlt; d.valsAlt = t;
   }

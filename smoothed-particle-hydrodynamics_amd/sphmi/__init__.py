@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SPHMI_LIB", os.path.join(_PKG, "libsphmi.so"))  # SPHMI_LIB: A/B builds of the same ABI
 HOST_LIB_PATH = os.path.join(_PKG, "libsphmi_host.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_NEIGHBOR_COUNT = 32
 LIQUID_PARTICLE, ELASTIC_PARTICLE, BOUNDARY_PARTICLE = 1, 2, 3
 
@@ -23,7 +23,7 @@ STAGE_NAMES = ["hash", "sort", "sort_post", "index", "find_neighbors", "density"
 
 
 class SphConfig(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("particleCount", C.c_int32),
+    _fields_ = [("abi_version", C.c_int32), ("particleCount", C.c_int32), ("capacity", C.c_int32),
                 ("gridCellsX", C.c_int32), ("gridCellsY", C.c_int32), ("gridCellsZ", C.c_int32),
                 ("gridCellCount", C.c_int32), ("cellIdMask", C.c_uint32)] + \
                [(n, C.c_float) for n in
@@ -34,6 +34,13 @@ class SphConfig(C.Structure):
                [(n, C.c_int32) for n in ["numOfElasticP", "elasticOffset", "muscleCount", "numOfMembranes",
                                          "maxIteration", "device"]] + \
                [("stream", C.c_void_p)]
+
+
+class SphSlab(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ["layerLo", "layerHi", "ghostLayers", "hasLower", "hasUpper", "globalIdBits"]]
+
+
+SLAB_RECORD_WORDS = 9
 
 
 class SphError(RuntimeError):
@@ -75,7 +82,8 @@ _STAGE_FUNCS = ["sph_run_clear_buffers", "sph_run_hash_particles", "sph_run_sort
 EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sph_step", "sph_update_muscles",
                     "sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index",
                     "sph_read_buffer", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
-                    "sph_reset_stage_times", "sph_last_error", "sph_abi_version"] + _STAGE_FUNCS
+                    "sph_reset_stage_times", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack",
+                    "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
                          "sphmi_generate_box", "sphmi_muscle_signal"]
@@ -87,6 +95,12 @@ def device_lib():
     if _dev is None:
         if not os.path.exists(LIB_PATH):
             raise SphError("libsphmi.so not built: the HIP extension is required (no CPU fallback exists)")
+        # PyTorch-ROCm ships its own copy of libamdhip64. If it is going to live in this process it must be loaded first,
+        # so that libsphmi.so binds to that same runtime; two HIP runtimes in one process do not both see the GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.sph_create.argtypes = [C.POINTER(SphConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_void_p)]
@@ -102,6 +116,11 @@ def device_lib():
         L.sph_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
         L.sph_get_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
         L.sph_last_error.restype = C.c_char_p
+        L.sph_slab_init.argtypes = [C.c_void_p, C.POINTER(SphSlab), C.c_void_p]
+        L.sph_slab_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.sph_slab_rebuild.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.sph_particle_count.argtypes = [C.c_void_p]
+        L.sph_slab_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _dev = L
     return _dev
 
@@ -282,6 +301,28 @@ class owHIPSolver:
         out = np.empty(need.value // np.dtype(_BUF_DTYPE[name]).itemsize, _BUF_DTYPE[name])
         self._chk(self._L.sph_read_buffer(self._h, name.encode(), _ptr(out), need.value, None))
         return out
+
+    # --- slab decomposition (include/sphmi.h, "Spatial decomposition") ---
+    def slab_init(self, slab, global_ids):
+        g = np.ascontiguousarray(global_ids, np.uint32)
+        return self._chk(self._L.sph_slab_init(self._h, C.byref(slab), _ptr(g)))
+
+    def slab_pack(self, msg_down_ptr, msg_up_ptr, cap_records):
+        counts = (C.c_int32 * 3)()
+        self._chk(self._L.sph_slab_pack(self._h, msg_down_ptr, msg_up_ptr, cap_records, counts))
+        return counts[0], counts[1], counts[2]
+
+    def slab_rebuild(self, recv_down_ptr, n_down, recv_up_ptr, n_up):
+        self._chk(self._L.sph_slab_rebuild(self._h, recv_down_ptr, n_down, recv_up_ptr, n_up))
+        self.N = self._L.sph_particle_count(self._h)
+        return self.N
+
+    def slab_read(self):
+        n = self._L.sph_particle_count(self._h)
+        pos, vel = np.empty((n, 4), np.float32), np.empty((n, 4), np.float32)
+        gid, owned = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        self._chk(self._L.sph_slab_read(self._h, _ptr(pos), _ptr(vel), _ptr(gid), _ptr(owned)))
+        return pos, vel, gid, owned
 
     def set_stage_timing(self, enable=True):
         return self._chk(self._L.sph_set_stage_timing(self._h, int(enable)))

@@ -1,0 +1,175 @@
+"""Slab decomposition over torch.distributed (RCCL on MI355X; gloo for CPU tests) — SURVEY.md §8e, DESIGN.md §5.
+
+One process per GPU. The global box is cut into z-slabs of whole cell layers; each rank advances its own layers plus
+`GHOST_LAYERS` ghost layers per side with the ordinary fused step and, once per step, sends the authoritative particles
+that now lie within `GHOST_LAYERS` of a cut to the neighbouring rank (two point-to-point messages per rank per step, each
+riding one xGMI link; no collective on the data path). Ghost zones are replaced wholesale by what arrives.
+
+Why 4 ghost layers: one PCISPH step propagates information over 6 neighbour hops (density 1, forces 2, and +1 per
+predict/correct half-iteration up to 6 for the last pressure force), each hop <= 31h/30, i.e. 6.2h < 4 cell layers (8h).
+Particles owned at the last rebuild therefore see exactly the inputs a single-GPU run would give them, and because the
+local arrays are kept sorted by global id the within-cell order is the global one: owned results are bit-identical to
+the single-solver run (tests/test_slab.py).
+
+The numerical work sits behind a tiny backend interface so that the exchange logic itself can be tested on CPU:
+  backend.count                         current local particle count
+  backend.step(iteration)               advance every local particle one step
+  backend.pack() -> (kept, msg_down, msg_up)   int32 tensors of 9 words per record (position, velocity, global id)
+  backend.rebuild(recv_down, recv_up)   new local set = kept + received, sorted by global id
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import SLAB_RECORD_WORDS, SphSlab, owHIPSolver
+
+GHOST_LAYERS = 4
+OPEN_LO, OPEN_HI = -(1 << 30), (1 << 30)  # the first / last slab own everything below / above
+
+
+def particle_layers(position, cfg):
+    """z cell coordinate exactly as hashParticles computes it (sphFluid.cl:199): (int)(z * hashGridCellSizeInv), f32."""
+    z = np.ascontiguousarray(position[:, 2], np.float32)
+    return (z * np.float32(cfg.hashGridCellSizeInv)).astype(np.int32)
+
+
+def balanced_cuts(layers, world, min_thickness=2 * GHOST_LAYERS):
+    """Cut the occupied layer range into `world` slabs of (nearly) equal particle count. Returns world+1 cut layers with
+    open ends; every slab must be at least 2*GHOST_LAYERS thick so that halos only ever involve direct neighbours."""
+    lo, hi = int(layers.min()), int(layers.max()) + 1
+    hist = np.bincount(layers - lo, minlength=hi - lo).astype(np.int64)
+    cum = np.cumsum(hist)
+    cuts = [lo]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        c = lo + int(np.searchsorted(cum, target)) + 1
+        c = max(c, cuts[-1] + min_thickness)
+        cuts.append(c)
+    cuts.append(hi)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b - a < min_thickness:
+            raise ValueError("slab [%d,%d) thinner than %d layers: too many ranks for this box" % (a, b, min_thickness))
+    return cuts
+
+
+def make_slab(cuts, rank, world, n_global):
+    s = SphSlab()
+    s.layerLo = OPEN_LO if rank == 0 else cuts[rank]
+    s.layerHi = OPEN_HI if rank == world - 1 else cuts[rank + 1]
+    s.ghostLayers = GHOST_LAYERS
+    s.hasLower = 1 if rank > 0 else 0
+    s.hasUpper = 1 if rank < world - 1 else 0
+    s.globalIdBits = max(1, int(n_global - 1).bit_length())
+    return s
+
+
+def local_indices(layers, slab):
+    """Global ids (ascending) of the particles a rank holds initially: its own layers plus the ghost layers."""
+    lo = slab.layerLo - slab.ghostLayers if slab.hasLower else OPEN_LO
+    hi = slab.layerHi + slab.ghostLayers if slab.hasUpper else OPEN_HI
+    return np.flatnonzero((layers >= lo) & (layers < hi)).astype(np.uint32)
+
+
+class HipSlabBackend:
+    """The MI355X backend: an owHIPSolver with head-room for a varying particle count; halo messages are torch tensors
+    in HBM that libsphmi's pack / rebuild kernels write and read directly (sph_slab_pack / sph_slab_rebuild)."""
+
+    def __init__(self, cfg, position, velocity, global_ids, slab, headroom=1.3):
+        import torch
+        self.torch = torch
+        n = position.shape[0]
+        cfg.particleCount = n
+        cfg.capacity = int(n * headroom) + 4096
+        self.solver = owHIPSolver(cfg, position, velocity)
+        self.solver.slab_init(slab, global_ids)
+        self.cap_records = cfg.capacity // 2
+        dev = torch.device("cuda", cfg.device)
+        self.msg_down = torch.empty(self.cap_records * SLAB_RECORD_WORDS, dtype=torch.int32, device=dev)
+        self.msg_up = torch.empty_like(self.msg_down)
+        self.device = dev
+
+    @property
+    def count(self):
+        return self.solver.N
+
+    def step(self, iteration):
+        self.solver.step(iteration)
+
+    def pack(self):
+        kept, nd, nu = self.solver.slab_pack(C.c_void_p(self.msg_down.data_ptr()), C.c_void_p(self.msg_up.data_ptr()),
+                                             self.cap_records)
+        return kept, self.msg_down[:nd * SLAB_RECORD_WORDS], self.msg_up[:nu * SLAB_RECORD_WORDS]
+
+    def rebuild(self, recv_down, recv_up):
+        def ptr_n(t):
+            if t is None or t.numel() == 0:
+                return None, 0
+            t = t.to(self.device).contiguous()
+            self._keep = getattr(self, "_keep", []) + [t]
+            return C.c_void_p(t.data_ptr()), t.numel() // SLAB_RECORD_WORDS
+        self._keep = []
+        pd, nd = ptr_n(recv_down)
+        pu, nu = ptr_n(recv_up)
+        n = self.solver.slab_rebuild(pd, nd, pu, nu)
+        self.solver.synchronize()  # the received tensors may be released after this
+        self._keep = []
+        return n
+
+    def owned_state(self):
+        pos, vel, gid, owned = self.solver.slab_read()
+        m = owned.astype(bool)
+        return gid[m], pos[m], vel[m]
+
+
+class SlabDecomposition:
+    """Drives one backend per rank: step, then the halo exchange with the two neighbouring ranks."""
+
+    def __init__(self, backend, rank, world, dist=None, comm_device=None):
+        import torch
+        self.torch = torch
+        self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
+        self.lower = rank - 1 if rank > 0 else None
+        self.upper = rank + 1 if rank < world - 1 else None
+        if comm_device is None:
+            comm_device = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+        self.comm_device = torch.device(comm_device) if comm_device == "cpu" else getattr(backend, "device", torch.device("cuda"))
+        self.bytes_sent = 0
+
+    def _to_comm(self, t):
+        return t if t.device == self.comm_device else t.to(self.comm_device)
+
+    def exchange(self):
+        torch, dist = self.torch, self.dist
+        kept, msg_down, msg_up = self.backend.pack()
+        if self.world == 1:
+            return self.backend.rebuild(None, None)
+        P = dist.P2POp
+        # 1. sizes (one int each way), 2. payloads of exactly that size; each phase is one batched group of isend/irecv
+        n_send = {self.lower: msg_down.numel(), self.upper: msg_up.numel()}
+        size_out = {p: torch.tensor([n_send[p]], dtype=torch.int32, device=self.comm_device) for p in (self.lower, self.upper) if p is not None}
+        size_in = {p: torch.zeros(1, dtype=torch.int32, device=self.comm_device) for p in size_out}
+        ops = []
+        for p in size_out:
+            ops += [P(dist.isend, size_out[p], p), P(dist.irecv, size_in[p], p)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        n_recv = {p: int(size_in[p].item()) for p in size_in}
+        payload_out = {self.lower: msg_down, self.upper: msg_up}
+        recv = {p: torch.empty(n_recv[p], dtype=torch.int32, device=self.comm_device) for p in n_recv}
+        ops, keep = [], []
+        for p in n_recv:
+            if n_send[p] > 0:
+                t = self._to_comm(payload_out[p]).contiguous()
+                keep.append(t)
+                ops.append(P(dist.isend, t, p))
+                self.bytes_sent += 4 * n_send[p]
+            if n_recv[p] > 0:
+                ops.append(P(dist.irecv, recv[p], p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return self.backend.rebuild(recv.get(self.lower), recv.get(self.upper))
+
+    def step(self, iteration):
+        self.backend.step(iteration)
+        return self.exchange()

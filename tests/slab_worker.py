@@ -1,0 +1,123 @@
+"""Worker for tests/test_slab.py: one rank of a 2-rank (or N-rank) slab-decomposed run.
+
+  python slab_worker.py --rank R --world W --port P --backend oracle|hip --steps K --out DIR
+
+backend "oracle" is a TEST-ONLY stand-in that advances the local particle set with oracle/sph_oracle.c (so the exchange
+logic in sphmi/slab.py runs on CPU under gloo); backend "hip" is the product path (libsphmi.so, HBM-resident messages).
+Each rank writes its OWNED particles (global id, position, velocity) to DIR/rank<R>.npz.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import scenes  # noqa: E402
+import sphmi  # noqa: E402
+from sphmi import slab as S  # noqa: E402
+
+REC = sphmi.SLAB_RECORD_WORDS
+
+
+def scene():
+    # wide-mode box, long in z: 30 cell layers, lattice with a little jitter so that particles cross the cut
+    return scenes.liquid_box((8.0, 8.0, 60.0), (12, 10, 110), mask=0xffffffff, jitter_in_r0=0.05)
+
+
+class OracleSlabBackend:
+    """numpy + oracle implementation of the backend interface of sphmi/slab.py (test infrastructure)."""
+
+    def __init__(self, cfg, position, velocity, global_ids, slab):
+        import torch
+        self.torch = torch
+        self.cfg, self.slab = cfg, slab
+        self.pos, self.vel, self.gid = position.copy(), velocity.copy(), global_ids.copy()
+        self.owned = self._owned(self.pos)
+
+    def _owned(self, pos):
+        lay = S.particle_layers(pos, self.cfg)
+        return (lay >= self.slab.layerLo) & (lay < self.slab.layerHi)
+
+    @property
+    def count(self):
+        return self.pos.shape[0]
+
+    def step(self, iteration):
+        from oracle import oraclebind as O
+        d = sphmi.config_dict(self.cfg)
+        d["N"] = d["particleCount"] = self.count
+        o = O.OracleSolver(d, self.pos, self.vel, threads=2)
+        o.step()
+        self.pos = o.buffer("position").reshape(-1, 4)[:self.count].copy()
+        self.vel = o.buffer("velocity").reshape(-1, 4)[:self.count].copy()
+        o.close()
+
+    def _records(self, m):
+        rec = np.concatenate([self.pos[m].view(np.int32), self.vel[m].view(np.int32), self.gid[m].view(np.int32)[:, None]], axis=1)
+        return self.torch.from_numpy(np.ascontiguousarray(rec).reshape(-1))
+
+    def pack(self):
+        lay = S.particle_layers(self.pos, self.cfg)
+        a = self.owned
+        down = a & (lay < self.slab.layerLo + self.slab.ghostLayers) & bool(self.slab.hasLower)
+        up = a & (lay >= self.slab.layerHi - self.slab.ghostLayers) & bool(self.slab.hasUpper)
+        self._kept = (self.pos[a], self.vel[a], self.gid[a])
+        return int(a.sum()), self._records(down), self._records(up)
+
+    def rebuild(self, recv_down, recv_up):
+        parts = [self._kept]
+        for t in (recv_down, recv_up):
+            if t is not None and t.numel():
+                r = t.cpu().numpy().reshape(-1, REC)
+                parts.append((r[:, 0:4].view(np.float32), r[:, 4:8].view(np.float32), r[:, 8].view(np.uint32)))
+        pos = np.concatenate([p[0] for p in parts]); vel = np.concatenate([p[1] for p in parts]); gid = np.concatenate([p[2] for p in parts])
+        order = np.argsort(gid, kind="stable")
+        assert np.unique(gid).size == gid.size, "duplicate particle after the halo exchange"
+        self.pos, self.vel, self.gid = np.ascontiguousarray(pos[order]), np.ascontiguousarray(vel[order]), gid[order]
+        self.owned = self._owned(self.pos)
+        return self.count
+
+    def owned_state(self):
+        return self.gid[self.owned], self.pos[self.owned], self.vel[self.owned]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--backend", choices=["oracle", "hip"], required=True)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % a.port, rank=a.rank, world_size=a.world)
+    sc = scene()
+    cfg = sc["cfg"]
+    n_global = cfg.particleCount
+    layers = S.particle_layers(sc["position"], cfg)
+    cuts = S.balanced_cuts(layers, a.world)
+    slab = S.make_slab(cuts, a.rank, a.world, n_global)
+    idx = S.local_indices(layers, slab)
+    pos, vel = sc["position"][idx], sc["velocity"][idx]
+    if a.backend == "hip":
+        cfg.device = 0
+        backend = S.HipSlabBackend(cfg, pos, vel, idx, slab)
+    else:
+        backend = OracleSlabBackend(cfg, pos, vel, idx, slab)
+    dd = S.SlabDecomposition(backend, a.rank, a.world, dist, comm_device="cpu")  # gloo: messages staged through host
+    counts = []
+    for it in range(a.steps):
+        counts.append(dd.step(it))
+    gid, p, v = backend.owned_state()
+    np.savez(os.path.join(a.out, "rank%d.npz" % a.rank), gid=gid, pos=p, vel=v, counts=np.array(counts),
+             cuts=np.array(cuts), sent=dd.bytes_sent)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

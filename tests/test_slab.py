@@ -1,0 +1,118 @@
+"""Multi-GPU path: slab decomposition + halo exchange of sphmi/slab.py.
+
+CPU: two gloo ranks advance their slabs with the oracle as numerical backend; the union of the owned particles must be
+bit-identical to a single-domain oracle run — this checks the decomposition itself (cuts, 4-layer ghost zone, ownership
+hand-over, global-id ordering, message format). GPU (-m gpu): the same with libsphmi's pack / rebuild kernels and
+HBM-resident messages, two ranks sharing the one card of the test box (gloo, host-staged transport; RCCL needs one GPU per
+rank and is exercised by bench.py --gpus N)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+import sphmi
+from sphmi import slab as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STEPS = 4
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(backend, world, out, steps=STEPS):
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "--rank", str(r), "--world", str(world),
+                               "--port", str(port), "--backend", backend, "--steps", str(steps), "--out", str(out)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+
+
+def single_domain_reference(steps=STEPS):
+    sys.path.insert(0, HERE)
+    import slab_worker
+    sc = slab_worker.scene()
+    o = scenes.oracle_for(sc, threads=8)
+    for _ in range(steps):
+        o.step()
+    n = sc["cfg"].particleCount
+    return sc, o.buffer("position").reshape(-1, 4)[:n], o.buffer("velocity").reshape(-1, 4)[:n]
+
+
+def check_union(results, sc, pos_ref, vel_ref):
+    n = sc["cfg"].particleCount
+    gid = np.concatenate([r["gid"] for r in results])
+    assert gid.size == n and np.unique(gid).size == n, "owned sets must partition the particles (%d of %d)" % (gid.size, n)
+    pos = np.concatenate([r["pos"] for r in results])
+    vel = np.concatenate([r["vel"] for r in results])
+    order = np.argsort(gid)
+    assert scenes.bits_equal(pos[order], pos_ref), scenes.diff_report(pos[order], pos_ref)
+    assert scenes.bits_equal(vel[order], vel_ref), scenes.diff_report(vel[order], vel_ref)
+    # the halo really carried particles, and both ranks hold more than they own (ghost layers)
+    assert all(int(r["sent"]) > 0 for r in results)
+    assert all(r["counts"][-1] > r["gid"].size for r in results)
+
+
+def test_partition_helpers():
+    sc = scenes.liquid_box((8.0, 8.0, 60.0), (12, 10, 110), mask=0xffffffff)
+    lay = S.particle_layers(sc["position"], sc["cfg"])
+    cuts = S.balanced_cuts(lay, 2)
+    assert len(cuts) == 3 and cuts[1] - cuts[0] >= 8 and cuts[2] - cuts[1] >= 8
+    slabs = [S.make_slab(cuts, r, 2, sc["cfg"].particleCount) for r in range(2)]
+    idx = [S.local_indices(lay, s) for s in slabs]
+    owned = [(lay[i] >= s.layerLo) & (lay[i] < s.layerHi) for i, s in zip(idx, slabs)]
+    assert sum(int(o.sum()) for o in owned) == sc["cfg"].particleCount  # owned sets partition the scene
+    assert all(i.size > o.sum() for i, o in zip(idx, owned))            # plus ghosts
+    assert np.all(np.diff(idx[0].astype(np.int64)) > 0)                 # ascending global id
+    with pytest.raises(ValueError):
+        S.balanced_cuts(lay, 16)                                        # slabs thinner than 2 * GHOST_LAYERS
+
+
+def test_two_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
+    results = run_ranks("oracle", 2, tmp_path)
+    sc, pos_ref, vel_ref = single_domain_reference()
+    check_union(results, sc, pos_ref, vel_ref)
+
+
+def test_three_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
+    results = run_ranks("oracle", 3, tmp_path, steps=3)
+    sc, pos_ref, vel_ref = single_domain_reference(steps=3)
+    check_union(results, sc, pos_ref, vel_ref)
+
+
+@pytest.mark.gpu
+def test_two_rank_halo_exchange_matches_single_domain_gpu(tmp_path):
+    results = run_ranks("hip", 2, tmp_path)
+    sc, pos_ref, vel_ref = single_domain_reference()
+    check_union(results, sc, pos_ref, vel_ref)
+
+
+@pytest.mark.gpu
+def test_single_rank_slab_backend_equals_plain_solver():
+    """world = 1: pack + rebuild every step (sort by global id) must not change anything."""
+    sc = scenes.liquid_box((8.0, 8.0, 20.0), (12, 10, 30), mask=0xffffffff, jitter_in_r0=0.05)
+    cfg = sc["cfg"]
+    n = cfg.particleCount
+    plain = scenes.hip_for(sc)
+    lay = S.particle_layers(sc["position"], cfg)
+    slab = S.make_slab([int(lay.min()), int(lay.max()) + 1], 0, 1, n)
+    cfg2 = scenes.liquid_box((8.0, 8.0, 20.0), (12, 10, 30), mask=0xffffffff, jitter_in_r0=0.05)["cfg"]
+    be = S.HipSlabBackend(cfg2, sc["position"], sc["velocity"], np.arange(n, dtype=np.uint32), slab)
+    dd = S.SlabDecomposition(be, 0, 1)
+    for it in range(3):
+        plain.step(it)
+        assert dd.step(it) == n
+    gid, pos, vel = be.owned_state()
+    assert np.array_equal(gid, np.arange(n))
+    assert scenes.bits_equal(pos, plain.read_position_buffer())
+    assert scenes.bits_equal(vel, plain.read_velocity_buffer())
