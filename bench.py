@@ -31,7 +31,14 @@ WORKLOADS = {
     "config2_1M_cube": ((50.0, 50.0, 50.0), (100, 100, 100), 0xffff),
     "tiny": ((8.0, 8.0, 8.0), (12, 10, 12), 0xffff),
     "cube_4M": ((80.0, 80.0, 80.0), (160, 160, 160), 0xffffffff),
+    "config4_16M_box": ((78.0, 50.0, 470.0), (160, 100, 1000), 0xffffffff),  # SURVEY 8(d) config #4, strong scaling
 }
+
+
+def weak_workload(world):
+    """N > 1 default: the config #2 column repeated `world` times along z (1.06M particles per GPU), wide cell ids,
+    cut into `world` z-slabs with a 4-layer halo exchanged once per step (sphmi/slab.py)."""
+    return (50.0, 50.0, 50.0 * world), (100, 100, 100 * world), 0xffffffff
 
 
 def host_cores():
@@ -79,20 +86,46 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # SPHMI_DIST_BACKEND=gloo lets several ranks share one card (functional rehearsal on a 1-GPU box: host-staged halo)
+        backend_name = os.environ.get("SPHMI_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend_name, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libsphmi has no CPU path")
     torch.cuda.set_device(local_rank)
 
-    box, lattice, mask = WORKLOADS[args.workload]
+    strong = world > 1 and args.workload != "config2_1M_cube"
+    if world > 1 and not strong:
+        box, lattice, mask = weak_workload(world)
+        workload_name = "weak_%dx_config2_column" % world
+    else:
+        box, lattice, mask = WORKLOADS[args.workload]
+        workload_name = args.workload
     sc = scenes.liquid_box(box, lattice, mask=mask)
     cfg = sc["cfg"]
     cfg.device = local_rank
     stream = torch.cuda.Stream(device=local_rank)
     cfg.stream = stream.cuda_stream  # the solver launches on this stream; torch events below are recorded on it
-    N = cfg.particleCount
-    solver = sphmi.owHIPSolver(cfg, sc["position"], sc["velocity"])
+    N = cfg.particleCount  # global particle count
+    decomposition = None
+    if world > 1:
+        from sphmi import slab as S
+        layers = S.particle_layers(sc["position"], cfg)
+        cuts = S.balanced_cuts(layers, world)
+        slab = S.make_slab(cuts, rank, world, N)
+        idx = S.local_indices(layers, slab)
+        backend = S.HipSlabBackend(cfg, sc["position"][idx], sc["velocity"][idx], idx, slab)
+        decomposition = S.SlabDecomposition(backend, rank, world, dist)
+        solver = backend.solver
+
+        class _Stepper:  # step + halo exchange
+            def step(self, it):
+                decomposition.step(it)
+        stepper = _Stepper()
+    else:
+        solver = sphmi.owHIPSolver(cfg, sc["position"], sc["velocity"])
+        stepper = solver
 
     def barrier():
         torch.cuda.synchronize()
@@ -102,24 +135,24 @@ def main():
 
     it = 0
     for _ in range(args.warmup):
-        solver.step(it); it += 1
+        stepper.step(it); it += 1
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
         for _ in range(args.steps):
-            solver.step(it); it += 1
+            stepper.step(it); it += 1
         ev1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     ms_per_step = wall * 1e3 / args.steps
-    value = N * world * args.steps / wall
+    value = N * args.steps / wall  # N = particles of the whole job (all ranks)
 
     # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
     stages_ms, roofline = {}, None
@@ -128,17 +161,18 @@ def main():
         solver.reset_stage_times()
         k2 = max(5, min(args.steps, 20))
         for _ in range(k2):
-            solver.step(it); it += 1
+            stepper.step(it); it += 1
         st = solver.stage_times()
         solver.set_stage_timing(False)
         stages_ms = {k: round(ms / k2, 5) for k, (ms, cnt) in st.items() if cnt}
         d_ms, d_cnt = st["density"]
+        n_local = solver.N  # particles this rank's density kernel processes per launch (incl. ghost layers when N > 1)
         if d_cnt:
-            achieved = N * DENSITY_BYTES_PER_PARTICLE / (d_ms / d_cnt * 1e-3) / 1e9
+            achieved = n_local * DENSITY_BYTES_PER_PARTICLE / (d_ms / d_cnt * 1e-3) / 1e9
             roofline = {"kernel": "k_density (pcisph_computeDensity)", "bound": "hbm", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": None, "avg_launch_us": round(d_ms / d_cnt * 1e3, 2),
-                        "bytes_per_launch": N * DENSITY_BYTES_PER_PARTICLE}
+                        "bytes_per_launch": n_local * DENSITY_BYTES_PER_PARTICLE}
             traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
             if os.path.exists(traffic_file):  # PMC result of the committed rocprofv3 passes (see profiles/README.md)
                 tr = json.load(open(traffic_file))
@@ -147,7 +181,7 @@ def main():
 
     # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
     cpu = None
-    if rank == 0 and args.cpu_steps > 0:
+    if rank == 0 and args.cpu_steps > 0 and world == 1:
         cores = host_cores()
         ora = scenes.oracle_for(sc, threads=cores)
         ora.step()  # warm-up (page faults, first-touch)
@@ -160,21 +194,24 @@ def main():
                          % (args.cpu_steps, N), "ms_per_step": round(cw * 1e3 / args.cpu_steps, 2)}
         ora.close()
 
-    solver.close()
     if rank == 0:
         out = {
             "metric": "particle-steps/sec (whole node)", "value": round(value, 1), "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "particles_per_gpu": N, "box_in_h": list(box),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload_name, "particles": N, "particles_per_gpu": N // world, "box_in_h": list(box),
                        "liquid_lattice": list(lattice), "cell_ids": "ref16" if mask == 0xffff else "wide",
                        "pcisph_iterations": cfg.maxIteration,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent boxes (replicas, no halo yet)" % world},
+                       "parallelism": "1 GPU" if world == 1 else
+                       "%d z-slabs, 4-layer halo, 2 RCCL send/recv per rank per step" % world},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms,
         }
         if cpu:
-            out["gpu_over_cpu"] = round(value / world / cpu["value"], 1)
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if decomposition is not None:
+            out["halo"] = {"local_particles_rank0": solver.N, "bytes_sent_rank0_per_step": decomposition.bytes_sent // max(1, it)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -168,6 +168,9 @@ class SlabDecomposition:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if self.comm_device.type == "cuda":
+            # RCCL completes on torch's communication stream; the rebuild kernels run on the solver's own stream
+            torch.cuda.synchronize(self.comm_device)
         return self.backend.rebuild(recv.get(self.lower), recv.get(self.upper))
 
     def step(self, iteration):
