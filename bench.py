@@ -176,8 +176,10 @@ def main():
             traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
             if os.path.exists(traffic_file):  # PMC result of the committed rocprofv3 passes (see profiles/README.md)
                 tr = json.load(open(traffic_file))
-                if tr.get("workload") == args.workload:
+                if tr.get("workload") == workload_name:
                     roofline["traffic"] = tr.get("hbm_bytes_per_launch")
+                elif workload_name in tr.get("other_workloads", {}):
+                    roofline["traffic"] = tr["other_workloads"][workload_name]["hbm_bytes_per_launch"]
 
     # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
     cpu = None

@@ -5,17 +5,21 @@
 // histogram of candidates with d^2 <= h^2, from which r_thr is chosen so that at most 32 remain (or 31h/30 if fewer
 // than 32 exist); pass 1 appends candidates with d^2 <= r_thr^2 in traversal order, at most 32.
 //
-// MI355X design (DESIGN.md §4.3): the reference walks ~640 candidates twice per particle and does the expensive part
+// MI355X design (DESIGN.md 4.3): the reference walks ~640 candidates twice per particle and does the expensive part
 // (sqrt, IEEE divide, histogram / store) under a branch that ~7 % of the lanes take but ~99 % of the waves execute.
-// Here a 256-thread workgroup owns 256 consecutive sorted particles, stages the <= 9 contiguous runs of sorted particles
-// that can contain their candidates (cells are contiguous along x in the sorted order) into LDS once, and each lane
-//   1. walks its 8 cells ONCE with a cheap filter d^2 <= max(h, 31h/30)^2 (a superset of both reference passes) and
-//      appends the LDS slot of every hit to a private list in LDS (compaction: ~45 of ~640 candidates survive),
-//   2. replays pass 0 and pass 1 of the reference over that short list, in traversal order, with every lane busy,
-//      using exactly the reference's float expressions (IEEE sqrt / divide), so r_thr, slot order and distances are
-//      bit-identical.
-// Lanes whose list overflows or whose cells are not fully staged (wrapped / aliased cells, LDS capacity) fall back to
-// the literal two-pass walk over global memory (`find_neighbors_slow`), so the result is exact in every case.
+// Here a 256-thread workgroup owns 128 consecutive sorted particles (two lanes per particle), stages the <= 9
+// contiguous runs of sorted particles that can contain their candidates (cells are contiguous along x in the sorted
+// order) into LDS once as SoA x/y/z, and each lane
+//   1. walks 4 of the particle's 8 cells ONCE, four candidates per trip (16-byte aligned LDS reads, packed-f32 math,
+//      next quad prefetched), with the cheap filter d^2 <= max(h, 31h/30)^2 — a superset of both reference passes — and
+//      appends the LDS slot of every hit to a private u16 list in LDS (compaction: ~45 of ~640 candidates survive),
+//   2. replays pass 0 / threshold / pass 1 of the reference over that short list in registers, in traversal order,
+//      with exactly the reference's float expressions, so r_thr, slot order and distances are bit-identical. Pass 0 does
+//      not build the histogram: the cumulative counts it needs are "d^2 < U[j]" tests against 30 thresholds computed
+//      exactly on the host (SphDev::binU), searched by bisection.
+// Particles whose list overflows or whose cells are not fully staged (wrapped / aliased cells, LDS capacity) are queued
+// and served by k_find_neighbors_fallback, the literal two-pass walk over global memory (`find_neighbors_slow`), so the
+// result is exact for any input.
 #include <stdlib.h>
 #include <string.h>
 
@@ -145,6 +149,7 @@ struct FnShared {
   uint16_t list[FN_LIST_CAP][FN_THREADS];         // [entry][lane] LDS slots of the filter hits, traversal order
   float binU[32];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j (see SphDev::binU)
   int rowLo[9], rowHi[9], rowBase[9];             // staged runs: sorted-index range and first LDS slot
+  int batchLo, batchHi, retry;                    // current batch of particles; retry: small-batch mode
 };
 
 // d.dbg layout: [0] particles handed to the fallback kernel because a cell was not staged, [1] because a list
@@ -153,7 +158,7 @@ struct FnShared {
 // Lane pair (2p, 2p+1) serves particle p: lane `half` walks the cells k = half, half+2, half+4, half+6 of the
 // reference's order, so the merged traversal order is A0 B1 A2 B3 A4 B5 A6 B7 and only four per-cell hit counts have
 // to cross lanes (one DPP swap each) to place every neighbour in the reference's slot.
-__global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint32_t* __restrict__ slowQueue, int experiment) {
+__global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint32_t* __restrict__ slowQueue) {
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
   const int tid = threadIdx.x;
@@ -162,10 +167,31 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   const int id = p0 + p;
   const bool alive = id < d.N;
 
-  // ---- stage the candidate runs. Cells of this workgroup lie in [cLo, cHi]; row r = (sy+1) + 3*(sz+1) holds the cells
-  // [cLo - 1, cHi + 1] shifted by sy*gx + sz*gx*gy, which is one contiguous run of sorted particles.
+  // ---- stage the candidate runs. Cells of a batch of particles lie in [cLo, cHi]; row r = (sy+1) + 3*(sz+1) holds the
+  // cells [cLo - 1, cHi + 1] shifted by sy*gx + sz*gx*gy, which is one contiguous run of sorted particles. Normally the
+  // batch is the whole workgroup (128 particles). Where those runs would not fit the LDS budget — the workgroup straddles
+  // two x-rows of cells (the runs then span whole rows) or sits in very dense cells — it serves its particles in smaller
+  // batches instead: at most 32 particles, never across an x-row boundary.
+  const int blockHi = min(p0 + FN_PART, d.N);
+  if (tid == 0) { sh.batchLo = p0; sh.retry = 0; }
+  while (true) {
+  __syncthreads();  // (also protects the LDS of the previous batch)
+  const int batchLo = sh.batchLo;
+  if (batchLo >= blockHi) break;  // uniform
+  if (tid < 64) {
+    int len = blockHi - batchLo;
+    if (sh.retry) {
+      const int i = batchLo + tid;
+      const unsigned row0 = d.keys[batchLo] / (unsigned)d.gx;
+      const bool stop = (tid >= 32) || (i >= blockHi) || (d.keys[i] / (unsigned)d.gx != row0);
+      len = __ffsll((long long)__ballot(stop)) - 1;  // first lane that must not join the batch (lane 32 at the latest)
+    }
+    if (tid == 0) sh.batchHi = batchLo + len;
+  }
+  __syncthreads();
+  const int batchHi = sh.batchHi;
   if (tid < 9) {
-    const int cLo = (int)d.keys[p0], cHi = (int)d.keys[min(p0 + FN_PART, d.N) - 1];
+    const int cLo = (int)d.keys[batchLo], cHi = (int)d.keys[batchHi - 1];
     const int sy = tid % 3 - 1, sz = tid / 3 - 1;
     const int shift = sy * d.gx + sz * d.gx * d.gy;
     const int a = max(cLo - 1 + shift, 0), b = min(cHi + 1 + shift, d.G - 1);
@@ -175,9 +201,20 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
   if (tid >= 64 && tid < 96) sh.binU[tid - 64] = d.binU[tid - 64];
   __syncthreads();
+  if (tid == 0 && !sh.retry) {
+    int total = 0;
+    for (int r = 0; r < 9; r++) total += sh.rowHi[r] - sh.rowLo[r];
+    if (total > FN_CAND_CAP) sh.retry = 2;  // 2 = "switch now": redo this workgroup in small batches
+  }
+  __syncthreads();
+  if (sh.retry == 2) {  // uniform
+    __syncthreads();
+    if (tid == 0) sh.retry = 1;
+    continue;
+  }
   if (tid == 0) {
     int base = 0;
-    // the own row (4) first, then the others: if LDS runs out, the most-used runs are the ones that are staged
+    // the own row (4) first, then the others: if LDS still runs out, the most-used runs are the ones that are staged
     const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
     for (int q = 0; q < 9; q++) {
       const int r = order[q];
@@ -198,7 +235,9 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     }
   }
   __syncthreads();
-  if (experiment == 1) return;  // timing experiment: staging only
+  if (tid == 0) sh.batchLo = batchHi;  // next batch (every thread has read batchLo / batchHi by now)
+  const bool mine_now = alive && id >= batchLo && id < batchHi;  // this lane's particle belongs to the current batch
+  if (!mine_now) continue;
 
   float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
   bool slow = false;
@@ -283,7 +322,6 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
 #undef FN_LOAD
 #undef FN_TEST
-  if (experiment == 2) { if (cnt == 12345) d.dbg[15] = 1; return; }  // timing experiment: staging + walk
   bool over = cnt > FN_LIST_CAP;
   over = over || (__shfl_xor((int)over, 1) != 0);
   if (over) {
@@ -334,7 +372,6 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   const int jb = (lo >= SPH_RSEG) ? SPH_RSEG : ((cAtHi == SPH_MAXN) ? lo : lo - 1);
   const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
   const float r2 = r_thr * r_thr;
-  if (experiment == 3) { if (r2 == 12345.f) d.dbg[15] = 1; return; }  // timing experiment: + threshold search
 
   // ---- 2b. pass 1: hits with d^2 <= r_thr^2 as a bit mask; per-cell counts by popcount; swap the four counts inside the
   // pair; every hit goes to (hits in earlier cells of the merged order) + (rank inside its cell). Slots >= 32 are
@@ -358,7 +395,6 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
       start[i] = run + (half ? theirs[i] : 0);
       run += mine[i] + theirs[i];
     }
-    if (experiment == 5) { if (run == 12345) d.dbg[15] = 1; return; }  // timing experiment: no write loop
     // walk the entries in list order with a running (cell start, index delta, rank inside the cell)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
     int32_t* const idBase = d.nbrId + (((size_t)(id >> 6) * 8 * 64 + (size_t)(id & 63)) << 2);
@@ -391,6 +427,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
   // ---- the rare particles the fast path cannot serve are queued for k_find_neighbors_fallback (exact, any input)
   if (alive && slow && half == 0) slowQueue[atomicAdd(&d.dbg[4], 1u)] = (uint32_t)id;
+  }  // batches
 }
 
 // Literal two-pass walk for the queued particles, at full occupancy (grid-stride over the queue).
@@ -411,10 +448,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_v1(SphDev d) {
 }
 
 int sphk_find_neighbors(sph_solver* s) {
-  static int variant = -1, experiment = 0;
+  static int variant = -1;
   if (variant < 0) {
-    const char* x = getenv("SPHMI_FN_EXPERIMENT");
-    experiment = x ? atoi(x) : 0;
     const char* e = getenv("SPHMI_FIND_NEIGHBORS");
     variant = (e && !strcmp(e, "v1")) ? 1 : 2;
   }
@@ -428,7 +463,7 @@ int sphk_find_neighbors(sph_solver* s) {
     }
     // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
     SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
-    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, s->d, s->d.keysAlt, experiment);
+    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, s->d, s->d.keysAlt);
     hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N), 2048)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
   }
   SPH_HIP(hipGetLastError());
