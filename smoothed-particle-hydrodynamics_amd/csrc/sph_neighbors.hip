@@ -430,12 +430,76 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }  // batches
 }
 
-// Literal two-pass walk for the queued particles, at full occupancy (grid-stride over the queue).
+// The queued particles, one WAVE per particle: the 64 lanes take consecutive candidates of a cell, so a particle costs
+// ~2 x 8 x 2 dependent memory round trips instead of ~1300. Same semantics as find_neighbors_slow: pass 0 fills a
+// 30-bin histogram (LDS atomics), every lane derives the same r_thr, pass 1 assigns slots in traversal order with a
+// ballot prefix (lane order == candidate order inside a chunk) and stops at 32.
 __global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_fallback(SphDev d, const uint32_t* __restrict__ slowQueue) {
-  __shared__ uint32_t hist[SPH_RSEG][SPH_BLOCK];
+  __shared__ uint32_t hist[SPH_BLOCK / 64][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t count = d.dbg[4];
-  for (uint32_t q = blockIdx.x * SPH_BLOCK + threadIdx.x; q < count; q += gridDim.x * SPH_BLOCK)
-    find_neighbors_slow(d, (int)slowQueue[q], &hist[0][threadIdx.x], SPH_BLOCK);
+  const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t q = blockIdx.x * (SPH_BLOCK / 64) + wave; q < count; q += gridDim.x * (SPH_BLOCK / 64)) {
+    const int id = (int)slowQueue[q];
+    const float4 me = d.sortedPos[id];
+    CellSet cs;
+    particle_cells(d, me, (int)d.keys[id], cs);
+    if (lane < 32) hist[wave][lane] = 0u;
+    const float h2 = d.h * d.h;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      for (int j0 = cs.lo[k]; j0 < cs.hi[k]; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < cs.hi[k] && j != id) {
+          const float4 o = d.sortedPos[j];
+          const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
+          const float d2 = ex * ex + ey * ey + ez * ez;
+          if (d2 <= h2) {
+            const float dist = sqrtf(d2);
+            const int bin = (int)(dist * (float)SPH_RSEG / d.h);
+            if (bin < SPH_RSEG) atomicAdd(&hist[wave][bin], 1u);
+          }
+        }
+      }
+    }
+    int jb = 0, sum = 0;  // threshold, sphFluid.cl:310-323 (LDS ops of one wave retire in order: the adds are visible)
+    while (jb < SPH_RSEG) {
+      sum += (int)hist[wave][jb];
+      if (sum == SPH_MAXN) break;
+      if (sum > SPH_MAXN) { jb--; break; }
+      jb++;
+    }
+    const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
+    const float r2 = r_thr * r_thr;
+    int found = 0;  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      for (int j0 = cs.lo[k]; j0 < cs.hi[k] && found < SPH_MAXN; j0 += 64) {
+        const int j = j0 + lane;
+        float d2 = 0.f;
+        bool hit = false;
+        if (j < cs.hi[k] && j != id) {
+          const float4 o = d.sortedPos[j];
+          const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
+          d2 = ex * ex + ey * ey + ez * ez;
+          hit = d2 <= r2;
+        }
+        const unsigned long long m = __ballot(hit);
+        const int pos = found + __popcll(m & ltMask);
+        if (hit && pos < SPH_MAXN) {
+          const size_t idx = nbr_index(id, pos);
+          d.nbrId[idx] = j;
+          d.nbrDist[idx] = sqrtf(d2) * d.simScale;
+        }
+        found += __popcll(m);
+      }
+    }
+    if (lane >= min(found, SPH_MAXN) && lane < SPH_MAXN) {
+      const size_t idx = nbr_index(id, lane);
+      d.nbrId[idx] = -1;
+      d.nbrDist[idx] = -1.f;
+    }
+  }
 }
 
 // Reference-shaped kernel (one lane per particle, everything from global memory); kept for A/B timing
@@ -464,7 +528,7 @@ int sphk_find_neighbors(sph_solver* s) {
     // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
     SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
     hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, s->d, s->d.keysAlt);
-    hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N), 2048)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
+    hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N, 4), 1024)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
   }
   SPH_HIP(hipGetLastError());
   return SPH_OK;
