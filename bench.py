@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2_1M_cube", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=80, help="steps of the CPU baseline, ~10 s on 16 cores (0 = skip)")
     ap.add_argument("--no-stage-pass", action="store_true", help="skip the second, per-stage-timed pass")
     args = ap.parse_args()
 
