@@ -91,6 +91,7 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend_name, rank=rank, world_size=world)
+        dist.barrier()  # creates the communicator with every rank present before the first point-to-point exchange
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libsphmi has no CPU path")
     torch.cuda.set_device(local_rank)
