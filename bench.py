@@ -214,7 +214,8 @@ def main():
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if decomposition is not None:
-            out["halo"] = {"local_particles_rank0": solver.N, "bytes_sent_rank0_per_step": decomposition.bytes_sent // max(1, it)}
+            out["halo"] = {"local_particles_rank0": solver.N, "bytes_sent_rank0_per_step": decomposition.bytes_sent // max(1, it),
+                           "exchange_host_ms_per_step_rank0": round(decomposition.exchange_seconds * 1e3 / max(1, it), 4)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

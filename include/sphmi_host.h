@@ -40,6 +40,15 @@ int sphmi_generate_box(const sph_config* cfg, double xmax_in_h, double ymax_in_h
                        float spacing, float ox, float oy, float oz, float jitter, uint64_t seed, float* position4N,
                        float* velocity4N);
 
+/* owHelper::loadConfigurationToFile (owHelper.cpp:1640-1672), the `-l_to` trajectory dump: `<dir>/position_buffer.txt` gets
+ * "numOfElasticP\nnumOfLiquidP\n" when firstIteration, then one `x\ty\tz\ttype` line per NON-boundary particle (appended
+ * on later calls; the reference calls it every 10th step, owPhysicsFluidSimulator.cpp:121-129); on the first call also
+ * `connection_buffer.txt` (32*numOfElasticP rows of 4 floats) and `membranes_buffer.txt` (count, then one row per
+ * triangle). Numbers are formatted by operator<< with the stream defaults, as in the reference. Deviation: the reference
+ * indexes the stride-3 membrane array with stride 4 (a bug, owHelper.cpp:1665); here each row is `i\tj\tk\t0`. */
+int sphmi_save_configuration(const char* dir, const float* position4N, int count, int numOfElasticP, int numOfLiquidP,
+                             const float* connections, const int32_t* membranes, int numOfMembranes, int firstIteration);
+
 /* Muscle activation of main_sim.py:4-53 / PyramidalSimulation.cpp:68-93 in closed form:
  * 96 values for step t, entries 96..muscleCount-1 left 0. */
 int sphmi_muscle_signal(int step, float* out, int muscleCount);

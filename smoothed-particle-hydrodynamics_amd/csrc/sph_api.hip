@@ -585,7 +585,7 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
   if (s->cfg.cellIdMask != 0xffffffffu) { sph_set_error("slab decomposition needs wide cell ids (cellIdMask = 0xffffffff)"); return SPH_ERR_INVALID; }
   if (s->d.hasElastic) { sph_set_error("slab decomposition supports pure-liquid scenes only"); return SPH_ERR_INVALID; }
   if (slab->layerLo >= slab->layerHi || slab->ghostLayers < 1 || slab->globalIdBits < 1 || slab->globalIdBits > 32) { sph_set_error("bad sph_slab"); return SPH_ERR_INVALID; }
-  s->slab = *slab; s->hasSlab = true;
+  s->slab = *slab; s->hasSlab = true; s->slabKept = -1;
   SPH_HIP(hipMemcpyAsync(s->d.gid, globalIds, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyHostToDevice, s->stream));
   // ownership flags from the initial positions: reuse the rebuild path with nothing received
   SPH_HIP(hipMemcpyAsync(s->d.sortedPos, s->d.posOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
@@ -607,6 +607,7 @@ extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t 
   SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
   SPH_HIP(hipStreamSynchronize(s->stream));
   counts[0] = (int32_t)h[0]; counts[1] = (int32_t)h[1]; counts[2] = (int32_t)h[2];
+  s->slabKept = (int)h[0];
   if ((int)h[1] > capRecords || (int)h[2] > capRecords) { sph_set_error("halo message overflow: %u / %u records, room for %d", h[1], h[2], capRecords); return SPH_ERR_SIZE; }
   return SPH_OK;
 }
@@ -614,12 +615,12 @@ extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t 
 extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp) {
   ENTER(s);
   if (!s->hasSlab || nDown < 0 || nUp < 0 || (nDown && !recvDown) || (nUp && !recvUp)) { sph_set_error("sph_slab_rebuild: bad arguments"); return SPH_ERR_INVALID; }
-  uint32_t h[4];
-  SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
-  SPH_HIP(hipStreamSynchronize(s->stream));
-  const long long total = (long long)h[0] + nDown + nUp;
+  if (s->slabKept < 0) { sph_set_error("sph_slab_rebuild without a preceding sph_slab_pack"); return SPH_ERR_ORDER; }
+  const int kept = s->slabKept;
+  s->slabKept = -1;
+  const long long total = (long long)kept + nDown + nUp;
   if (total > s->capacity || total <= 0) { sph_set_error("slab holds %lld particles after the exchange, capacity %d", total, s->capacity); return SPH_ERR_SIZE; }
-  return sphk_slab_rebuild(s, (const uint32_t*)recvDown, nDown, (const uint32_t*)recvUp, nUp, (int)h[0]);
+  return sphk_slab_rebuild(s, (const uint32_t*)recvDown, nDown, (const uint32_t*)recvUp, nUp, kept);
 }
 
 extern "C" int sph_slab_read(sph_solver* s, float* position4, float* velocity4, uint32_t* globalIds, uint32_t* owned) {

@@ -70,6 +70,7 @@ struct sph_solver {
   int capTiles;              // ceil(capacity/64)
   sph_slab slab; bool hasSlab;
   uint32_t* slabCounts;      // device: kept / down / up counters
+  int slabKept;              // host copy of the kept count of the last sph_slab_pack (-1: none pending)
   // radix-sort workspace
   uint32_t* blockHist;       // [256][maxSortBlocks] block histograms + 256 digit totals
   int maxSortBlocks;

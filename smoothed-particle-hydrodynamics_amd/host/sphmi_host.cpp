@@ -276,6 +276,43 @@ int sphmi_generate_box(const sph_config* cfg, double xm, double ym, double zm, i
   return (i == (size_t)nl + (size_t)nb) ? SPH_OK : SPH_ERR_SIZE;
 }
 
+int sphmi_save_configuration(const char* dir, const float* position, int count, int numOfElasticP, int numOfLiquidP,
+                             const float* connections, const int32_t* membranes, int numOfMembranes, int firstIteration) {
+  if (!dir || !position || count <= 0) return SPH_ERR_INVALID;
+  const std::string base = std::string(dir) + "/";
+  std::ofstream positionFile;
+  if (firstIteration) {  // owHelper.cpp:1643-1649
+    positionFile.open((base + "position_buffer.txt").c_str(), std::ofstream::trunc);
+    positionFile << numOfElasticP << "\n";
+    positionFile << numOfLiquidP << "\n";
+  } else {
+    positionFile.open((base + "position_buffer.txt").c_str(), std::ofstream::app);
+  }
+  if (!positionFile.is_open()) return SPH_ERR_INVALID;
+  for (int i = 0; i < count; i++) {
+    if ((int)position[4 * i + 3] != SPH_BOUNDARY_PARTICLE)
+      positionFile << position[i * 4 + 0] << "\t" << position[i * 4 + 1] << "\t" << position[i * 4 + 2] << "\t"
+                   << position[i * 4 + 3] << "\n";
+  }
+  positionFile.close();
+  if (firstIteration) {
+    if (connections && numOfElasticP > 0) {
+      std::ofstream connectionFile((base + "connection_buffer.txt").c_str(), std::ofstream::trunc);
+      const int con_num = SPH_MAX_NEIGHBOR_COUNT * numOfElasticP;
+      for (int i = 0; i < con_num; i++)
+        connectionFile << connections[4 * i + 0] << "\t" << connections[4 * i + 1] << "\t" << connections[4 * i + 2] << "\t"
+                       << connections[4 * i + 3] << "\n";
+    }
+    if (membranes && numOfMembranes > 0) {
+      std::ofstream membranesFile((base + "membranes_buffer.txt").c_str(), std::ofstream::trunc);
+      membranesFile << numOfMembranes << "\n";
+      for (int i = 0; i < numOfMembranes; i++)
+        membranesFile << membranes[3 * i + 0] << "\t" << membranes[3 * i + 1] << "\t" << membranes[3 * i + 2] << "\t" << 0 << "\n";
+    }
+  }
+  return SPH_OK;
+}
+
 int sphmi_muscle_signal(int step, float* out, int muscleCount) {
   if (!out || muscleCount < 96) return SPH_ERR_INVALID;
   for (int i = 0; i < muscleCount; i++) out[i] = 0.f;

@@ -68,6 +68,8 @@ def host_lib():
         L.sphmi_generate_box.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
         L.sphmi_muscle_signal.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.sphmi_save_configuration.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int]
         _host = L
     return _host
 
@@ -86,7 +88,7 @@ EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sp
                     "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
-                         "sphmi_generate_box", "sphmi_muscle_signal"]
+                         "sphmi_generate_box", "sphmi_muscle_signal", "sphmi_save_configuration"]
 
 
 def device_lib():
@@ -186,6 +188,19 @@ def generate_box(cfg, lx, ly, lz, spacing=None, origin=None, jitter=0.0, seed=20
         raise SphError("sphmi_generate_box failed: %d" % rc)
     cfg.particleCount = n
     return pos, vel, dict(numOfLiquidP=nl.value, numOfElasticP=0, numOfBoundaryP=nb.value)
+
+
+def save_configuration(directory, position, num_elastic, num_liquid, connections=None, membranes=None, first=True):
+    """owHelper::loadConfigurationToFile (owHelper.cpp:1640-1672): the `-l_to` trajectory dump."""
+    pos = np.ascontiguousarray(position, np.float32)
+    con = None if connections is None else np.ascontiguousarray(connections, np.float32)
+    mem = None if membranes is None else np.ascontiguousarray(membranes, np.int32)
+    rc = host_lib().sphmi_save_configuration(directory.encode(), pos.ctypes.data, pos.shape[0], num_elastic, num_liquid,
+                                             None if con is None else con.ctypes.data,
+                                             None if mem is None else mem.ctypes.data,
+                                             0 if mem is None else mem.shape[0], int(first))
+    if rc:
+        raise SphError("sphmi_save_configuration failed: %d" % rc)
 
 
 def muscle_signal(step, muscle_count=100):

@@ -101,18 +101,18 @@ class HipSlabBackend:
         return kept, self.msg_down[:nd * SLAB_RECORD_WORDS], self.msg_up[:nu * SLAB_RECORD_WORDS]
 
     def rebuild(self, recv_down, recv_up):
+        keep = []  # the received tensors must outlive the asynchronous rebuild kernels: released at the next rebuild
+
         def ptr_n(t):
             if t is None or t.numel() == 0:
                 return None, 0
             t = t.to(self.device).contiguous()
-            self._keep = getattr(self, "_keep", []) + [t]
+            keep.append(t)
             return C.c_void_p(t.data_ptr()), t.numel() // SLAB_RECORD_WORDS
-        self._keep = []
         pd, nd = ptr_n(recv_down)
         pu, nu = ptr_n(recv_up)
         n = self.solver.slab_rebuild(pd, nd, pu, nu)
-        self.solver.synchronize()  # the received tensors may be released after this
-        self._keep = []
+        self._keep = keep
         return n
 
     def owned_state(self):
@@ -174,5 +174,9 @@ class SlabDecomposition:
         return self.backend.rebuild(recv.get(self.lower), recv.get(self.upper))
 
     def step(self, iteration):
+        import time
         self.backend.step(iteration)
-        return self.exchange()
+        t0 = time.perf_counter()
+        n = self.exchange()
+        self.exchange_seconds = getattr(self, "exchange_seconds", 0.0) + time.perf_counter() - t0  # host time incl. waits
+        return n

@@ -85,6 +85,26 @@ def test_text_loader_roundtrip(tmp_path):
         sphmi.load_configuration(str(tmp_path / "missing.txt"), str(vf))
 
 
+def test_trajectory_dump_format(tmp_path):
+    """buffers/*.txt of the reference's -l_to mode (owHelper.cpp:1640-1672): header, non-boundary particles only, appended
+    frames, default operator<< float formatting (6 significant digits)."""
+    sc = scenes.SCENES["tiny_elastic"]()
+    n_el, n_liq = sc["numOfElasticP"], sc["numOfLiquidP"]
+    sphmi.save_configuration(str(tmp_path), sc["position"], n_el, n_liq, sc["elastic"], sc["membranes"], first=True)
+    sphmi.save_configuration(str(tmp_path), sc["position"], n_el, n_liq, first=False)
+    lines = (tmp_path / "position_buffer.txt").read_text().split("\n")
+    assert lines[0] == str(n_el) and lines[1] == str(n_liq)
+    body = [l for l in lines[2:] if l]
+    assert len(body) == 2 * (n_el + n_liq)  # two frames, boundary particles skipped
+    first = np.array([float(v) for v in body[0].split("\t")], np.float32)
+    np.testing.assert_allclose(first, sc["position"][0], rtol=1e-5)
+    assert body[0].split("\t")[3] == "2.1"  # 6 significant digits, no padding
+    con = (tmp_path / "connection_buffer.txt").read_text().strip().split("\n")
+    assert len(con) == 32 * n_el and con[-1].split("\t")[0] == "-1"
+    mem = (tmp_path / "membranes_buffer.txt").read_text().strip().split("\n")
+    assert int(mem[0]) == sc["membranes"].shape[0] and [int(v) for v in mem[1].split("\t")] == list(sc["membranes"][0]) + [0]
+
+
 def test_muscle_signal_closed_form():
     """main_sim.py:4-53 in closed form (parity unpinned: the Python-2 script cannot run here; formula by inspection)."""
     s0 = sphmi.muscle_signal(0)
