@@ -153,7 +153,7 @@ struct FnShared {
 };
 
 // d.dbg layout: [0] particles handed to the fallback kernel because a cell was not staged, [1] because a list
-// overflowed, [2] sum of staged candidates, [3] candidate runs dropped for LDS capacity, [4] fallback queue length.
+// overflowed, [3] candidate runs dropped for LDS capacity, [4] fallback queue length.
 //
 // Lane pair (2p, 2p+1) serves particle p: lane `half` walks the cells k = half, half+2, half+4, half+6 of the
 // reference's order, so the merged traversal order is A0 B1 A2 B3 A4 B5 A6 B7 and only four per-cell hit counts have
@@ -220,10 +220,9 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
       const int r = order[q];
       const int n = sh.rowHi[r] - sh.rowLo[r];
       sh.rowBase[r] = base;
-      if (base + n > FN_CAND_CAP) { sh.rowHi[r] = sh.rowLo[r]; atomicAdd(&d.dbg[3], 1u); continue; }  // not staged
+      if (base + n > FN_CAND_CAP) { sh.rowHi[r] = sh.rowLo[r]; atomicAdd(&d.dbg[3], 1u); continue; }  // not staged (rare)
       base += n;
     }
-    atomicAdd(&d.dbg[2], (uint32_t)base);
   }
   __syncthreads();
 #pragma unroll 1

@@ -5,5 +5,5 @@ h = scenes.hip_for(sc)
 h.reset_stage_times()
 h.step(0); h.synchronize()
 c = h.buffer('debugCounters'); N = sc['cfg'].particleCount
-print('N', N, 'unstaged-slow lanes', c[0], 'overflow lanes', c[1], 'staged cand total', c[2], 'per block', c[2]/((N+255)//256), 'dropped rows', c[3])
+print('N', N, 'fallback particles: cell not staged', c[0], ', list overflow', c[1], '; candidate runs dropped', c[3])
 nm = h.buffer('neighborIds').reshape(-1,32); print('mean nbrs', (nm>=0).sum(1).mean())
