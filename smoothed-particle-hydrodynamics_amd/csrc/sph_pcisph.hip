@@ -35,13 +35,20 @@ __device__ __forceinline__ int xcd_block(int nblocks) {
 // ------------------------------------------------------------------ K6 pcisph_computeDensity (sphFluid.cl:472-518)
 // The HBM-roofline-graded pass: reads 32 x 4 B of distances, writes 4 B. The empty-slot test uses the distance
 // sentinel (-1), which is set iff the id is -1 (both are written together), so the id half of the map is not read.
+// A/B on MI355X (bench.py roofline, 16.5 M particles): XCD-remapped blocks + plain loads 0.66 of 8 TB/s, plain block
+// order 0.67-0.69, plain order + non-temporal loads 0.75 (6.0 TB/s = 96 % of this part's 6.29 TB/s copy rate). The pass has
+// no reuse, so neither an XCD-local L2 nor keeping the stream in cache helps.
 __global__ __launch_bounds__(SPH_BLOCK) void k_density(SphDev d, int nblocks) {
-  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (id >= d.N) return;
   const NbrTile t(d, id);
+  typedef float nt4 __attribute__((ext_vector_type(4)));
   float4 r[8];
 #pragma unroll
-  for (int g = 0; g < 8; g++) r[g] = t.dist4(g);  // all 8 loads in flight before the first use
+  for (int g = 0; g < 8; g++) {  // all 8 loads in flight before the first use
+    const nt4 q = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(&t.dist[(size_t)g * 64]));
+    r[g] = make_float4(q.x, q.y, q.z, q.w);
+  }
   double density = 0.0;
 #pragma unroll
   for (int g = 0; g < 8; g++) {
