@@ -40,6 +40,20 @@ static int dev_alloc(T** p, size_t count) {
   return SPH_OK;
 }
 
+SphDev sph_ranged(const sph_solver* s, int ghostDepth) {
+  SphDev d = s->d;
+  d.rangeLo = 0; d.rangeHi = d.G;
+  if (s->hasSlab && ghostDepth >= 0) {
+    const long long layerCells = (long long)d.gx * d.gy;
+    long long lo = (long long)s->slab.layerLo - ghostDepth, hi = (long long)s->slab.layerHi + ghostDepth;
+    if (lo < 0) lo = 0;
+    if (hi > d.gz) hi = d.gz;
+    if (hi < lo) hi = lo;
+    d.rangeLo = (int)(lo * layerCells); d.rangeHi = (int)(hi * layerCells);
+  }
+  return d;
+}
+
 static int bit_length(uint32_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
 // Radial-histogram bin of a squared distance exactly as findNeighbors computes it (sphFluid.cl:159-160):
@@ -218,6 +232,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   d.del2W = cfg->del2WviscosityCoefficient;
   d.numElastic = cfg->numOfElasticP; d.elasticOffset = cfg->elasticOffset; d.muscleCount = cfg->muscleCount;
   d.numMembranes = cfg->numOfMembranes; d.hasElastic = cfg->numOfElasticP > 0;
+  d.rangeLo = 0; d.rangeHi = d.G;
 
   s->capacity = cap;
   s->capTiles = (cap + SPH_TILE - 1) / SPH_TILE;
@@ -421,14 +436,23 @@ extern "C" int sph_step(sph_solver* s, int iterationCount) {
   RUN(SPH_ST_HASH, sphk_hash(s));
   RUN(SPH_ST_SORT, sphk_sort(s));
   RUN(SPH_ST_SORT_POST, sphk_sort_post_and_index(s));
-  RUN(SPH_ST_FIND_NEIGHBORS, sphk_find_neighbors(s));
-  RUN(SPH_ST_DENSITY, sphk_density(s));
-  RUN(SPH_ST_FORCES, sphk_forces(s, true));
+  // Slab mode: a stage runs only on the ghost layers its results are needed on (owned layers + depth layers per side).
+  // Information travels one neighbour hop (<= 31h/30, i.e. 31/60 of a 2h cell layer) per stage, backwards from the owned
+  // layers: with `left` predict-correct iterations still to come, the pressure force is needed 2*left hops out and
+  // predictDensity 2*left + 1; density 1 hop; the neighbour lists as far as the first predictDensity; forces on the owned
+  // layers only; the iteration-0 predicted positions one hop further than anything else (k_ghost_init: everywhere).
+  const bool slab = s->hasSlab;
+  const int M = s->cfg.maxIteration;
+  auto layersFor = [&](int hops) { return slab ? min((hops * 31 + 59) / 60, s->slab.ghostLayers) : -1; };
+  RUN(SPH_ST_FIND_NEIGHBORS, sphk_find_neighbors(s, layersFor(2 * (M - 1) + 1)));
+  RUN(SPH_ST_DENSITY, sphk_density(s, layersFor(1)));
+  if (slab) RUN(SPH_ST_FORCES, sphk_ghost_init(s));
+  RUN(SPH_ST_FORCES, sphk_forces(s, true, layersFor(0)));
   if (s->d.hasElastic) RUN(SPH_ST_ELASTIC, sphk_elastic(s));
-  for (int iter = 0; iter < s->cfg.maxIteration; iter++) {
-    const bool last = iter == s->cfg.maxIteration - 1;
-    RUN(SPH_ST_PREDICT_DENSITY, sphk_predict_density(s, true));
-    RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force(s, last ? 2 : 1));
+  for (int iter = 0; iter < M; iter++) {
+    const int left = M - 1 - iter;  // iterations after this one
+    RUN(SPH_ST_PREDICT_DENSITY, sphk_predict_density(s, true, layersFor(2 * left + 1)));
+    RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force(s, left == 0 ? 2 : 1, layersFor(2 * left)));
   }
   if (s->d.hasElastic) {
     RUN(SPH_ST_MEMBRANES, sphk_clear_membranes(s));
@@ -585,6 +609,10 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
   if (s->cfg.cellIdMask != 0xffffffffu) { sph_set_error("slab decomposition needs wide cell ids (cellIdMask = 0xffffffff)"); return SPH_ERR_INVALID; }
   if (s->d.hasElastic) { sph_set_error("slab decomposition supports pure-liquid scenes only"); return SPH_ERR_INVALID; }
   if (slab->layerLo >= slab->layerHi || slab->ghostLayers < 1 || slab->globalIdBits < 1 || slab->globalIdBits > 32) { sph_set_error("bad sph_slab"); return SPH_ERR_INVALID; }
+  if ((2 * s->cfg.maxIteration * 31 + 59) / 60 > slab->ghostLayers) {  // 2*maxIteration hops of 31h/30 must fit the ghost zone
+    sph_set_error("ghostLayers = %d is too thin for maxIteration = %d", slab->ghostLayers, s->cfg.maxIteration);
+    return SPH_ERR_INVALID;
+  }
   s->slab = *slab; s->hasSlab = true; s->slabKept = -1;
   SPH_HIP(hipMemcpyAsync(s->d.gid, globalIds, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyHostToDevice, s->stream));
   // ownership flags from the initial positions: reuse the rebuild path with nothing received

@@ -39,6 +39,8 @@ struct SphDev {  // what the kernels see; passed by value
   double massGradW;    // ((double)mass)*gradWspikyCoefficient (sphFluid.cl:1194)
   double del2W;        // del2WviscosityCoefficient
   double closeR;       // 0.5*(hScaled/2) as the double the comparison at sphFluid.cl:1166 uses
+  int rangeLo, rangeHi;  // a launch serves the sorted particles of cells [rangeLo, rangeHi): all of them ([0, G)) except in
+                         // slab mode, where ghost layers that a stage's results are not needed on are skipped (sph_api.hip)
   int numElastic, elasticOffset, muscleCount, numMembranes;
   int hasElastic;      // 0: membrane kernels are no-ops and are folded into integrate
   // buffers
@@ -100,6 +102,19 @@ void sph_set_error(const char* fmt, ...);
 
 static inline int sph_blocks(int n, int per = SPH_BLOCK) { return (n + per - 1) / per; }
 
+// SphDev for a launch restricted to the owned layers plus `ghostDepth` ghost layers per side (slab mode; otherwise and
+// for ghostDepth < 0 the whole particle set).
+SphDev sph_ranged(const sph_solver* s, int ghostDepth);
+
+#ifdef __HIPCC__
+// id of the linear-th particle of the launch's range; false past its end
+__device__ __forceinline__ bool sph_range_id(const SphDev& d, int linear, int& id) {
+  const int begin = (int)d.cellStart[d.rangeLo], end = (int)d.cellStart[d.rangeHi];
+  id = begin + linear;
+  return id < end;
+}
+#endif
+
 // index of (sorted particle id, slot) in the tiled neighbour map
 __host__ __device__ static inline size_t nbr_index(int id, int slot) {
   return ((((size_t)(id >> 6) * 8 + (size_t)(slot >> 2)) * 64 + (size_t)(id & 63)) << 2) + (size_t)(slot & 3);
@@ -116,14 +131,15 @@ int sphk_index_fixed(sph_solver* s);      // H2 table (cellStart)
 int sphk_sort_post_and_index(sph_solver* s);  // fused K3 + K4 + H2
 // sph_neighbors.hip
 int sphk_clear_neighbors(sph_solver* s);
-int sphk_find_neighbors(sph_solver* s);
+int sphk_find_neighbors(sph_solver* s, int ghostDepth = -1);
 // sph_pcisph.hip
-int sphk_density(sph_solver* s);
-int sphk_forces(sph_solver* s, bool fusePredict);
+int sphk_density(sph_solver* s, int ghostDepth = -1);
+int sphk_forces(sph_solver* s, bool fusePredict, int ghostDepth = -1);
+int sphk_ghost_init(sph_solver* s);  // what K7 does besides the acceleration, for every particle (slab mode)
 int sphk_predict_positions(sph_solver* s);
-int sphk_predict_density(sph_solver* s, bool fuseCorrect);
+int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth = -1);
 int sphk_correct_pressure(sph_solver* s);
-int sphk_pressure_force(sph_solver* s, int fuse);  // 0 none, 1 + predictPositions, 2 + integrate
+int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth = -1);  // 0 none, 1 + predictPositions, 2 + integrate
 int sphk_integrate(sph_solver* s);
 // sph_slab.hip
 int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords);

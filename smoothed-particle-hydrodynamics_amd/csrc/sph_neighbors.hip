@@ -163,16 +163,18 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
   const int tid = threadIdx.x;
   const int p = tid >> 1, half = tid & 1;
-  const int p0 = blockIdx.x * FN_PART;
+  const int rangeBegin = (int)d.cellStart[d.rangeLo], rangeEnd = (int)d.cellStart[d.rangeHi];  // all particles, or fewer ghost layers
+  const int p0 = rangeBegin + blockIdx.x * FN_PART;
+  if (p0 >= rangeEnd) return;  // uniform
   const int id = p0 + p;
-  const bool alive = id < d.N;
+  const bool alive = id < rangeEnd;
 
   // ---- stage the candidate runs. Cells of a batch of particles lie in [cLo, cHi]; row r = (sy+1) + 3*(sz+1) holds the
   // cells [cLo - 1, cHi + 1] shifted by sy*gx + sz*gx*gy, which is one contiguous run of sorted particles. Normally the
   // batch is the whole workgroup (128 particles). Where those runs would not fit the LDS budget — the workgroup straddles
   // two x-rows of cells (the runs then span whole rows) or sits in very dense cells — it serves its particles in smaller
   // batches instead: at most 32 particles, never across an x-row boundary.
-  const int blockHi = min(p0 + FN_PART, d.N);
+  const int blockHi = min(p0 + FN_PART, rangeEnd);
   if (tid == 0) { sh.batchLo = p0; sh.retry = 0; }
   while (true) {
   __syncthreads();  // (also protects the LDS of the previous batch)
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_v1(SphDev d) {
   find_neighbors_slow(d, id, &hist[0][threadIdx.x], SPH_BLOCK);
 }
 
-int sphk_find_neighbors(sph_solver* s) {
+int sphk_find_neighbors(sph_solver* s, int ghostDepth) {
   static int variant = -1;
   if (variant < 0) {
     const char* e = getenv("SPHMI_FIND_NEIGHBORS");
@@ -526,7 +528,7 @@ int sphk_find_neighbors(sph_solver* s) {
     }
     // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
     SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
-    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, s->d, s->d.keysAlt);
+    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, sph_ranged(s, ghostDepth), s->d.keysAlt);
     hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N, 4), 1024)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
   }
   SPH_HIP(hipGetLastError());

@@ -25,6 +25,9 @@ struct NbrTile {
 // XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs; remap so that each
 // XCD works on one contiguous eighth of the sorted particle range and its L2 holds only that slab's neighbourhood.
 __device__ __forceinline__ int xcd_block(int nblocks) {
+#ifdef NO_XCD_REMAP
+  return blockIdx.x;
+#endif
   const int b = blockIdx.x;
   const int per = nblocks >> 3;  // blocks per XCD in the evenly divisible part
   const int even = per << 3;
@@ -39,8 +42,8 @@ __device__ __forceinline__ int xcd_block(int nblocks) {
 // order 0.67-0.69, plain order + non-temporal loads 0.75 (6.0 TB/s = 96 % of this part's 6.29 TB/s copy rate). The pass has
 // no reuse, so neither an XCD-local L2 nor keeping the stream in cache helps.
 __global__ __launch_bounds__(SPH_BLOCK) void k_density(SphDev d, int nblocks) {
-  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
+  int id;
+  if (!sph_range_id(d, blockIdx.x * SPH_BLOCK + threadIdx.x, id)) return;
   const NbrTile t(d, id);
   typedef float nt4 __attribute__((ext_vector_type(4)));
   float4 r[8];
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_density(SphDev d, int nblocks) {
   d.rho[id] = (float)density;
 }
 
-int sphk_density(sph_solver* s) {
+int sphk_density(sph_solver* s, int ghostDepth) {
   const int nb = sph_blocks(s->d.N);
-  hipLaunchKernelGGL(k_density, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  hipLaunchKernelGGL(k_density, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, sph_ranged(s, ghostDepth), nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -101,8 +104,8 @@ int sphk_predict_positions(sph_solver* s) {
 // ------------------------------------------------------------------ K7 pcisph_computeForcesAndInitPressure (sphFluid.cl:589-708)
 template <bool FUSE_PREDICT>
 __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
-  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
+  int id;
+  if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
   const float4 xi = d.sortedPos[id];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
@@ -162,11 +165,29 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pack_vel_rho(SphDev d) {
   d.velRho[id] = make_float4(v.x, v.y, v.z, d.rho[id]);
 }
 
-int sphk_forces(sph_solver* s, bool fusePredict) {
+// Slab mode: forces are only needed on the owned layers, but every local particle needs what K7 does besides the
+// acceleration — pressure = 0, pressure acceleration = 0 and (fused) the iteration-0 predicted position.
+__global__ __launch_bounds__(SPH_BLOCK) void k_ghost_init(SphDev d) {
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  d.accP[id] = zero;
+  d.pressure[id] = 0.f;
+  d.predPos[id] = predict_position(d, d.sortedPos[id], d.sortedVel[id], zero);
+}
+
+int sphk_ghost_init(sph_solver* s) {
+  hipLaunchKernelGGL(k_ghost_init, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+int sphk_forces(sph_solver* s, bool fusePredict, int ghostDepth) {
   const int nb = sph_blocks(s->d.N);
+  const SphDev d = sph_ranged(s, ghostDepth);
   hipLaunchKernelGGL(k_pack_vel_rho, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d);
-  if (fusePredict) hipLaunchKernelGGL((k_forces<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
-  else hipLaunchKernelGGL((k_forces<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  if (fusePredict) hipLaunchKernelGGL((k_forces<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  else hipLaunchKernelGGL((k_forces<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -182,8 +203,8 @@ __device__ __forceinline__ float corrected_pressure(const SphDev& d, float p, fl
 
 template <bool FUSE_CORRECT>
 __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nblocks) {
-  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
+  int id;
+  if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
   const float4 xi = d.predPos[id];
   const NbrTile t(d, id);
   double density = 0.0;
@@ -217,10 +238,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   }
 }
 
-int sphk_predict_density(sph_solver* s, bool fuseCorrect) {
+int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth) {
   const int nb = sph_blocks(s->d.N);
-  if (fuseCorrect) hipLaunchKernelGGL((k_predict_density<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
-  else hipLaunchKernelGGL((k_predict_density<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  const SphDev d = sph_ranged(s, ghostDepth);
+  if (fuseCorrect) hipLaunchKernelGGL((k_predict_density<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  else hipLaunchKernelGGL((k_predict_density<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -323,8 +345,8 @@ int sphk_integrate(sph_solver* s) {
 // (sphFluid.cl:1101-1212). FUSE: 0 = alone, 1 = + next iteration's predictPositions, 2 = + integrate (last iteration).
 template <int FUSE>
 __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblocks) {
-  const int id = xcd_block(nblocks) * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
+  int id;
+  if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
   const float4 xi = d.sortedPos[id];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
@@ -365,11 +387,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   if (FUSE == 2) integrate_particle(d, id, xi, d.sortedVel[id], d.acc[id], ap);
 }
 
-int sphk_pressure_force(sph_solver* s, int fuse) {
+int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth) {
   const int nb = sph_blocks(s->d.N);
-  if (fuse == 0) hipLaunchKernelGGL((k_pressure_force<0>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
-  else if (fuse == 1) hipLaunchKernelGGL((k_pressure_force<1>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
-  else hipLaunchKernelGGL((k_pressure_force<2>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
+  const SphDev d = sph_ranged(s, ghostDepth);
+  if (fuse == 0) hipLaunchKernelGGL((k_pressure_force<0>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  else if (fuse == 1) hipLaunchKernelGGL((k_pressure_force<1>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  else hipLaunchKernelGGL((k_pressure_force<2>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
