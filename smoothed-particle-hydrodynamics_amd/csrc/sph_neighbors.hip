@@ -185,7 +185,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     if (sh.retry) {
       const int i = batchLo + tid;
       const unsigned row0 = d.keys[batchLo] / (unsigned)d.gx;
-      const bool stop = (tid >= 32) || (i >= blockHi) || (d.keys[i] / (unsigned)d.gx != row0);
+      const bool stop = (tid >= 32) || (i >= blockHi) || (d.keys[min(i, blockHi - 1)] / (unsigned)d.gx != row0);
       len = __ffsll((long long)__ballot(stop)) - 1;  // first lane that must not join the batch (lane 32 at the latest)
     }
     if (tid == 0) sh.batchHi = batchLo + len;
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
 #undef FN_LOAD
 #undef FN_TEST
   bool over = cnt > FN_LIST_CAP;
-  over = over || (__shfl_xor((int)over, 1) != 0);
+  const int partnerOver = __shfl_xor((int)over, 1);  // unconditional: both lanes of the pair must take part in the swap
+  over = over || (partnerOver != 0);
   if (over) {
     if (half == 0 && !slow) atomicAdd(&d.dbg[1], 1u);
     slow = true;

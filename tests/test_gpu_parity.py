@@ -222,6 +222,42 @@ def test_ragged_sizes_and_single_particle_cells():
         assert_same(canon_hip(hip, N), canon_ora(ora, N), "lattice %s" % (lattice,), FUSED_SKIP)
 
 
+def test_overcrowded_cells_take_the_fallback_paths():
+    """Far more than 32 candidates within h and ~700 particles per cell: every compaction list overflows (fallback kernel,
+    one wave per particle), candidate runs exceed the LDS budget (small batches), radial bins overflow 32 at the first bin."""
+    sc = scenes.liquid_box((8.0, 8.0, 8.0), (18, 18, 18), spacing_in_r0=0.45, origin_in_r0=(4.0, 4.0, 4.0))
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=8)
+    hip.reset_stage_times()
+    for it in range(2):
+        hip.step(it)
+        ora.step()
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "overcrowded step %d" % it, FUSED_SKIP)
+    c = hip.buffer("debugCounters")
+    assert c[1] > 1000, "the list-overflow fallback was expected to be exercised (got %d)" % c[1]
+    nm = hip.buffer("neighborIds").reshape(-1, 32)
+    assert (nm[:, 31] >= 0).sum() > 1000  # many full lists
+
+
+def test_coincident_particles_neighbour_search():
+    """Particles at identical positions (d = 0): found as each other's first-bin neighbours with distance 0; compared up to
+    the density pass (beyond it the reference divides by r = 0, sphFluid.cl:1172-1178)."""
+    sc = scenes.liquid_box((8.0, 8.0, 8.0), (12, 10, 12), jitter_in_r0=0.03)
+    pos = sc["position"].copy()
+    pos[5:10, :3] = pos[200:205, :3]  # five coincident pairs
+    sc["position"] = pos
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc)
+    for st in scenes.STAGE_SEQUENCE[:scenes.STAGE_SEQUENCE.index("computeDensity") + 1]:
+        getattr(hip, scenes.HIP_STAGE_METHOD[st])()
+        ora.run(st)
+    got, want = canon_hip(hip, N), canon_ora(ora, N)
+    for k in ("particleIndex", "gridCellIndexFixedUp", "neighborIds", "neighborDist", "rho"):
+        assert scenes.bits_equal(got[k], want[k]), (k, scenes.diff_report(got[k], want[k]))
+    d = want["neighborDist"].reshape(-1, 32)
+    assert (d == 0.0).sum() >= 10
+
+
 def test_error_behaviour():
     """C-ABI error convention (include/sphmi.h): status codes, no exceptions across the ABI, order contract."""
     sc = scenes.SCENES["tiny"]()
