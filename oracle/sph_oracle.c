@@ -516,6 +516,7 @@ static f4 project_to_plane(f4 ps, f4 pa, f4 pb, f4 pc) {
 static void st_memb(sph_oracle* s) {
   const sph_oracle_params* p = &s->p;
   const int N = p->N;
+  if (!s->pml || !s->membraneData) return;  /* no membrane lists: the reference has no buffers to run this kernel on */
   const float r0 = p->r0;
 #pragma omp parallel for schedule(static) num_threads(s->p.threads)
   for (int id = 0; id < N; id++) {

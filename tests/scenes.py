@@ -99,6 +99,24 @@ def elastic_sheet_box(box_in_h=(8.0, 8.0, 8.0), lattice=(10, 8, 10), sheet=(8, 8
                 numOfLiquidP=int(liq.shape[0]), numOfElasticP=E, numOfBoundaryP=int(bnd_p.shape[0]))
 
 
+def elastic_offset_box():
+    """File-mode ordering (boundary, elastic, liquid; configuration/position.txt) with springs but no membranes: the
+    elastic kernel then addresses particleIndexBack[index + numOfBoundaryP] (owOpenCLSolver.cpp:435)."""
+    sc = elastic_sheet_box(muscles=True)
+    E, nl = sc["numOfElasticP"], sc["numOfLiquidP"]
+    pos, vel = sc["position"], sc["velocity"]
+    nb = pos.shape[0] - E - nl
+    order = np.concatenate([np.arange(E + nl, E + nl + nb), np.arange(E), np.arange(E, E + nl)])
+    el = sc["elastic"].copy()
+    live = el[:, 0] >= 0
+    el[live, 0] = el[live, 0] + np.float32(nb)  # partners are orig ids: shifted by the boundary block now in front
+    cfg = sc["cfg"]
+    cfg.elasticOffset = nb
+    cfg.numOfMembranes = 0
+    return dict(cfg=cfg, position=np.ascontiguousarray(pos[order]), velocity=np.ascontiguousarray(vel[order]), elastic=el,
+                membranes=None, particle_membranes=None, numOfLiquidP=nl, numOfElasticP=E, numOfBoundaryP=nb)
+
+
 # name -> builder. Sizes chosen so that the C oracle finishes 10 steps in well under a second.
 SCENES = {
     "tiny": lambda: liquid_box((8.0, 8.0, 8.0), (12, 10, 12)),

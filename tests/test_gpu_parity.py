@@ -258,6 +258,36 @@ def test_coincident_particles_neighbour_search():
     assert (d == 0.0).sum() >= 10
 
 
+@pytest.mark.parametrize("iterations", [1, 2, 4])
+def test_other_predict_correct_iteration_counts(iterations):
+    """maxIteration (owPhysicsConstant.h:76) is a run-time parameter here: the fused step must follow the oracle for
+    1, 2 and 4 predict-correct iterations too (different fusion pattern: the last pressure force carries integrate)."""
+    sc = scenes.SCENES["tiny_compressed"]()
+    sc["cfg"].maxIteration = iterations
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc)
+    for it in range(3):
+        hip.step(it)
+        ora.step()
+    assert_same(canon_hip(hip, N), canon_ora(ora, N), "maxIteration=%d" % iterations, FUSED_SKIP)
+
+
+def test_elastic_particles_behind_the_boundary_block():
+    """elasticOffset = numOfBoundaryP (file-mode particle order, owOpenCLSolver.cpp:435), springs + muscle, no membranes."""
+    sc = scenes.elastic_offset_box()
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc)
+    for it in range(5):
+        hip.step(it)
+        ora.step()
+        sig = sphmi.muscle_signal(it)
+        hip.updateMuscleActivityData(sig)
+        ora.update_muscles(sig)
+    assert_same(canon_hip(hip, N), canon_ora(ora, N), "elastic offset", FUSED_SKIP)
+    acc = canon_ora(ora, N)["acceleration"]
+    assert np.abs(acc).max() > 0
+
+
 def test_error_behaviour():
     """C-ABI error convention (include/sphmi.h): status codes, no exceptions across the ABI, order contract."""
     sc = scenes.SCENES["tiny"]()
