@@ -139,7 +139,9 @@ __device__ __forceinline__ void find_neighbors_slow(const SphDev& d, int id, uin
 #define FN_CAND_CAP 4096    // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
 #endif
 #define FN_CAND_PAD 8       // the aligned, prefetching 4-wide walk reads (never uses) up to 7 slots past a cell
-#define FN_LIST_CAP 48      // compaction list entries per lane (u16: 48 KB per workgroup)
+#ifndef FN_LIST_CAP
+#define FN_LIST_CAP 48      // compaction list entries per lane (u16 [entry][lane])
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -155,9 +157,9 @@ struct FnShared {
 // d.dbg layout: [0] particles handed to the fallback kernel because a cell was not staged, [1] because a list
 // overflowed, [3] candidate runs dropped for LDS capacity, [4] fallback queue length.
 //
-// Lane pair (2p, 2p+1) serves particle p: lane `half` walks the cells k = half, half+2, half+4, half+6 of the
-// reference's order, so the merged traversal order is A0 B1 A2 B3 A4 B5 A6 B7 and only four per-cell hit counts have
-// to cross lanes (one DPP swap each) to place every neighbour in the reference's slot.
+// Lane pair (2p, 2p+1) serves particle p: lane 0 walks the cells k = 0,5,6,7 of the reference's order and lane 1 the
+// cells 1,2,3,4, so the merged traversal order is A0 B1 B2 B3 B4 A5 A6 A7 and only four per-cell hit counts have to
+// cross lanes (one DPP swap each) to place every neighbour in the reference's slot.
 __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint32_t* __restrict__ slowQueue) {
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
@@ -259,7 +261,10 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
         if (r >= 0 && cs.lo[k] >= sh.rowLo[r] && cs.hi[k] <= sh.rowHi[r]) base = sh.rowBase[r] + (cs.lo[k] - sh.rowLo[r]);
         else slow = true;  // a non-empty cell of this particle is not in LDS (both lanes of the pair see this)
       }
-      if ((k & 1) == half) { num[k >> 1] = n; ldsLo[k >> 1] = base; absDelta[k >> 1] = cs.lo[k] - base; }
+      // lane 0 of the pair walks cells {0,5,6,7}, lane 1 cells {1,2,3,4}: both get four cells and about half of the hits
+      // (own cell ~42 %, each face neighbour ~14 %, edge ~5 %, corner ~2 %), so neither list is much longer than the other
+      const int owner = (k == 0 || k >= 5) ? 0 : 1, slot = (k == 0) ? 0 : (k >= 5 ? k - 4 : k - 1);
+      if (owner == half) { num[slot] = n; ldsLo[slot] = base; absDelta[slot] = cs.lo[k] - base; }
       if (k == 0 && half == 0) selfSlot = base + (id - cs.lo[0]);  // the particle itself sits in its own cell
     }
   }
@@ -391,12 +396,14 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
 #pragma unroll
   for (int i = 0; i < 4; i++) theirs[i] = __shfl_xor(mine[i], 1);
   if (alive && !slow) {
-    int start[4], run = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // merged order: (lane 0, i), (lane 1, i), (lane 0, i+1), ...
-      start[i] = run + (half ? theirs[i] : 0);
-      run += mine[i] + theirs[i];
-    }
+    // merged (reference) order of the 8 cells: A0 | B1 B2 B3 B4 | A5 A6 A7, where A = lane 0 and B = lane 1 of the pair
+    int start[4];
+    const int sumMine = mine[0] + mine[1] + mine[2] + mine[3], sumTheirs = theirs[0] + theirs[1] + theirs[2] + theirs[3];
+    const int run = sumMine + sumTheirs;
+    if (half == 0) { start[0] = 0; start[1] = mine[0] + sumTheirs; }
+    else { start[0] = theirs[0]; start[1] = start[0] + mine[0]; }
+    start[2] = start[1] + mine[1];
+    start[3] = start[2] + mine[2];
     // walk the entries in list order with a running (cell start, index delta, rank inside the cell)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
     int32_t* const idBase = d.nbrId + (((size_t)(id >> 6) * 8 * 64 + (size_t)(id & 63)) << 2);
