@@ -148,7 +148,7 @@ extern "C" int sph_get_stage_times(sph_solver* s, double* ms_total, int64_t* lau
 // ---------------------------------------------------------------------------------------------- create / destroy
 static void free_all(sph_solver* s) {
   SphDev& d = s->d;
-  void* ptrs[] = {d.velRho, d.bndMask, d.posPress, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
+  void* ptrs[] = {d.elasticMask, d.velRho, d.bndMask, d.posPress, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
                   d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho, d.rhoPred,
                   d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
                   s->blockHist};
@@ -255,7 +255,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(binU, 32);
   d.binU = binU;
   if (d.hasElastic) {
-    A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);
+    A(d.elasticMask, n); A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);
     if (membraneData && pml && cfg->numOfMembranes > 0) { A(d.membraneData, (size_t)3 * cfg->numOfMembranes); A(d.pml, (size_t)7 * d.numElastic); }
   }
 #undef A

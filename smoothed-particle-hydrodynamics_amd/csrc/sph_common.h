@@ -47,6 +47,7 @@ struct SphDev {  // what the kernels see; passed by value
   float4 *posOrig, *velOrig, *membDelta;
   float4 *sortedPos, *sortedVel, *predPos, *acc, *accP;
   float4* velRho;     // (sortedVel.xyz, rho): what the forces kernel gathers per neighbour besides the position
+  uint32_t* elasticMask;  // bit k set: neighbour slot k holds an elastic particle (forces kernel -> membrane kernel)
   uint32_t* bndMask;  // bit k set: neighbour slot k holds a boundary particle (written by the forces kernel, read by integrate)
   float4* posPress;  // (sortedPos.xyz, pressure): what the pressure-force kernel gathers per neighbour, one 16-B load
   uint32_t *keys, *vals, *keysAlt, *valsAlt, *backIndex;

@@ -78,63 +78,103 @@ __device__ __forceinline__ bool project_to_plane(const float4 ps, const float4 p
   return false;  // the reference prints and abandons this particle (:1296-1298,1468-1472)
 }
 
-__global__ __launch_bounds__(SPH_BLOCK) void k_membranes(SphDev d) {
+// Two kernels. k_membrane_collect queues the liquid particles that have an elastic neighbour (bit mask from the forces
+// kernel); k_membranes then gives every queued particle HALF A WAVE: lane = neighbour slot, so the expensive part — up to
+// 7 triangle projections per elastic neighbour — runs in parallel over the slots instead of serially in one lane (the
+// one-lane-per-particle form left 63 lanes waiting for the one next to a membrane: 0.27 ms of the worm scene's 0.81 ms).
+// The per-slot results are then combined by one lane in slot order, i.e. with the reference's summation order.
+__global__ __launch_bounds__(SPH_BLOCK) void k_membrane_collect(SphDev d, uint32_t* __restrict__ queue, uint32_t* __restrict__ count) {
+  __shared__ uint32_t local, base;
+  if (threadIdx.x == 0) local = 0u;
+  __syncthreads();
   const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
-  if ((int)d.sortedPos[id].w != SPH_LIQUID_PARTICLE) return;  // only liquid particles are displaced (:1395)
-  const uint32_t src = d.vals[id];
-  const float4 me = d.posOrig[src];  // the just-integrated position (:1436,1466)
-  float ncx = 0.f, ncy = 0.f, ncz = 0.f, wsum = 0.f, wsum2 = 0.f;
-  int jc = 0;
-  for (int nc = 0; nc < SPH_MAXN; nc++) {
-    const int jd = d.nbrId[nbr_index(id, nc)];
-    if (jd == -1) break;  // stops at the first empty slot (:1557)
-    if ((int)d.sortedPos[jd].w != SPH_ELASTIC_PARTICLE) continue;
-    const uint32_t jsrc = d.vals[jd];
-    const float4 pj = d.posOrig[jsrc];
-    const float vx = me.x - pj.x, vy = me.y - pj.y, vw = me.w - pj.w;  // .z zeroed, .w kept (:1436-1438)
-    const float dist = sqrtf(((vx * vx + vy * vy) + 0.f * 0.f) + vw * vw);
-    float mx = 0.f, my = 0.f, mz = 0.f;
+  uint32_t slot = 0xffffffffu;
+  if (id < d.N && (int)d.sortedPos[id].w == SPH_LIQUID_PARTICLE && d.elasticMask[id] != 0u) slot = atomicAdd(&local, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) base = local ? atomicAdd(count, local) : 0u;
+  __syncthreads();
+  if (slot != 0xffffffffu) queue[base + slot] = (uint32_t)id;
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_membranes(SphDev d, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count) {
+  __shared__ float sm[SPH_BLOCK / 32][32][4];  // per half-wave: (mx, my, mz, dist) of each slot
+  const int lane = threadIdx.x & 31, group = threadIdx.x >> 5;            // 32 lanes = the 32 neighbour slots of one particle
+  const uint32_t total = *count;
+  const uint32_t groups = gridDim.x * (SPH_BLOCK / 32);
+  for (uint32_t q = blockIdx.x * (SPH_BLOCK / 32) + group; q < ((total + 1u) & ~1u); q += groups) {  // both halves of a wave iterate together
+    const bool live = q < total;
+    const int id = live ? (int)queue[q] : 0;
+    const uint32_t ela = live ? d.elasticMask[id] : 0u;
+    const uint32_t src = d.vals[id];
+    const float4 me = d.posOrig[src];  // the just-integrated position (:1436,1466)
+    bool active = live && ((ela >> lane) & 1u);
+    bool failed = false;  // projection onto a degenerate triangle / zero-length normal: the reference abandons the particle
+    float mx = 0.f, my = 0.f, mz = 0.f, dist = 0.f;
     int ijk = 0;
-    for (int mli = 0; mli < SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE; mli++) {
-      const int mdi = d.pml[(size_t)jsrc * SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE + mli];
-      if (!(mdi > -1)) break;
-      const float4 pi_ = d.posOrig[d.membraneData[mdi * 3 + 0]];
-      const float4 pj_ = d.posOrig[d.membraneData[mdi * 3 + 1]];
-      const float4 pk_ = d.posOrig[d.membraneData[mdi * 3 + 2]];
-      f3 pp;
-      if (!project_to_plane(me, pi_, pj_, pk_, &pp)) return;
-      const float nx = me.x - pp.x, ny = me.y - pp.y, nz = me.z - pp.z;
-      const float len = sqrtf(nx * nx + ny * ny + nz * nz);
-      if (!(len > 0.f)) return;  // "error #001" path (:1501-1505)
-      mx += nx / len; my += ny / len; mz += nz / len;
-      ijk++;
+    if (active) {
+      const int jd = d.nbrId[nbr_index(id, lane)];
+      const uint32_t jsrc = d.vals[jd];
+      const float4 pj = d.posOrig[jsrc];
+      const float vx = me.x - pj.x, vy = me.y - pj.y, vw = me.w - pj.w;  // .z zeroed, .w kept (:1436-1438)
+      dist = sqrtf(((vx * vx + vy * vy) + 0.f * 0.f) + vw * vw);
+      for (int mli = 0; mli < SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE; mli++) {
+        const int mdi = d.pml[(size_t)jsrc * SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE + mli];
+        if (!(mdi > -1)) break;
+        const float4 pi_ = d.posOrig[d.membraneData[mdi * 3 + 0]];
+        const float4 pj_ = d.posOrig[d.membraneData[mdi * 3 + 1]];
+        const float4 pk_ = d.posOrig[d.membraneData[mdi * 3 + 2]];
+        f3 pp;
+        if (!project_to_plane(me, pi_, pj_, pk_, &pp)) { failed = true; break; }
+        const float nx = me.x - pp.x, ny = me.y - pp.y, nz = me.z - pp.z;
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        if (!(len > 0.f)) { failed = true; break; }  // "error #001" path (:1501-1505)
+        mx += nx / len; my += ny / len; mz += nz / len;
+        ijk++;
+      }
+      if (ijk > 0) { mx /= (float)ijk; my /= (float)ijk; mz /= (float)ijk; }
     }
-    if (ijk > 0) {
-      mx /= (float)ijk; my /= (float)ijk; mz /= (float)ijk;
-      // second loop of the reference (:1578-1591), applied as each membrane neighbour is finished: same order, same sums
-      const float w = fmaxf(0.f, (d.r0 - dist) / d.r0);
-      ncx += mx * w; ncy += my * w; ncz += mz * w;
-      wsum += w;
-      wsum2 += w * (d.r0 - dist);
-      jc++;
+    // The reference walks the slots in order and returns at the FIRST failure, before anything is written; a failure in
+    // any slot therefore abandons the particle (later slots cannot undo it, earlier ones have written nothing yet).
+    const unsigned long long failMask = __ballot(failed);
+    const unsigned long long halfMask = 0xffffffffull << (group & 1 ? 32 : 0);
+    sm[group][lane][0] = mx; sm[group][lane][1] = my; sm[group][lane][2] = mz; sm[group][lane][3] = dist;
+    const unsigned long long useMask = __ballot(active && ijk > 0);
+    __builtin_amdgcn_wave_barrier();  // LDS writes above are read by lane 0 of the half below (same wave: in order)
+    if (lane == 0 && live && !(failMask & halfMask)) {
+      const uint32_t use = (uint32_t)((useMask & halfMask) >> (group & 1 ? 32 : 0));
+      float ncx = 0.f, ncy = 0.f, ncz = 0.f, wsum = 0.f, wsum2 = 0.f;
+      for (int nc = 0; nc < SPH_MAXN; nc++) {  // second loop of the reference (:1578-1591): slot order
+        if (!((use >> nc) & 1u)) continue;
+        const float dd = sm[group][nc][3];
+        const float w = fmaxf(0.f, (d.r0 - dd) / d.r0);
+        ncx += sm[group][nc][0] * w; ncy += sm[group][nc][1] * w; ncz += sm[group][nc][2] * w;
+        wsum += w;
+        wsum2 += w * (d.r0 - dd);
+      }
+      if (use) {
+        float len = ((ncx * ncx + ncy * ncy) + ncz * ncz) + 0.f * 0.f;
+        if (len != 0.f) {
+          len = sqrtf(len);
+          float4 o = d.membDelta[src];
+          o.x += 1.0f * ((ncx / len) * wsum2) / wsum;
+          o.y += 1.0f * ((ncy / len) * wsum2) / wsum;
+          o.z += 1.0f * ((ncz / len) * wsum2) / wsum;
+          d.membDelta[src] = o;
+        }
+      }
     }
-  }
-  if (jc == 0) return;
-  float len = ((ncx * ncx + ncy * ncy) + ncz * ncz) + 0.f * 0.f;
-  if (len != 0.f) {
-    len = sqrtf(len);
-    float4 o = d.membDelta[src];
-    o.x += 1.0f * ((ncx / len) * wsum2) / wsum;
-    o.y += 1.0f * ((ncy / len) * wsum2) / wsum;
-    o.z += 1.0f * ((ncz / len) * wsum2) / wsum;
-    d.membDelta[src] = o;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 int sphk_membranes(sph_solver* s) {
   if (!s->d.hasElastic) return SPH_OK;  // no elastic neighbours can exist: the kernel would touch nothing
-  hipLaunchKernelGGL(k_membranes, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  // queue: keysAlt is idle after the sort; counter: dbg[5]
+  uint32_t* queue = s->d.keysAlt;
+  uint32_t* count = s->d.dbg + 5;
+  SPH_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s->stream));
+  hipLaunchKernelGGL(k_membrane_collect, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d, queue, count);
+  hipLaunchKernelGGL(k_membranes, dim3(min(sph_blocks(s->d.N, SPH_BLOCK / 32), 2048)), dim3(SPH_BLOCK), 0, s->stream, s->d, queue, count);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }

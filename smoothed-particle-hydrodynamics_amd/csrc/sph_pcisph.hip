@@ -116,7 +116,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
   const float4 vi = d.sortedVel[id];
   const NbrTile t(d, id);
   float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
-  uint32_t bnd = 0u;  // which neighbour slots hold boundary particles: saves integrate 32 type gathers per particle
+  uint32_t bnd = 0u, ela = 0u;  // which neighbour slots hold boundary / elastic particles: saves integrate and the
+                                // membrane kernel 32 type gathers per particle
 #pragma unroll 2
   for (int g = 0; g < 8; g++) {
     const int4 j4 = t.id4(g);
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
       if (jd != -1) {
         const float4 xj = d.sortedPos[jd];
         if (TYPE_OF(xj) == SPH_BOUNDARY_PARTICLE) bnd |= 1u << (g * 4 + k);
+        if (TYPE_OF(xj) == SPH_ELASTIC_PARTICLE) ela |= 1u << (g * 4 + k);
         if (rr[k] < d.hs) {
           const float4 vj = d.velRho[jd];      // (v.xyz, rho); for a boundary neighbour v is its wall normal (sphFluid.cl:653)
           const float rj = vj.w;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
     }
   }
   d.bndMask[id] = bnd;
+  if (d.hasElastic) d.elasticMask[id] = ela;
   const float scale = d.massMu * (float)(d.del2W / (double)d.rho[id]);
   float4 a;
   a.x = sx * scale + d.gravx + tx;
