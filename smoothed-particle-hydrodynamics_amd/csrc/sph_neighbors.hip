@@ -138,6 +138,7 @@ __device__ __forceinline__ void find_neighbors_slow(const SphDev& d, int id, uin
 #ifndef FN_CAND_CAP
 #define FN_CAND_CAP 4096    // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
 #endif
+#define FN_WIN 16           // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
 #define FN_CAND_PAD 8       // the aligned, prefetching 4-wide walk reads (never uses) up to 7 slots past a cell
 #ifndef FN_LIST_CAP
 #define FN_LIST_CAP 48      // compaction list entries per lane (u16 [entry][lane])
@@ -151,6 +152,9 @@ struct FnShared {
   uint16_t list[FN_LIST_CAP][FN_THREADS];         // [entry][lane] LDS slots of the filter hits, traversal order
   float binU[32];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j (see SphDev::binU)
   int rowLo[9], rowHi[9], rowBase[9];             // staged runs: sorted-index range and first LDS slot
+  int win[9][FN_WIN];                             // cellStart[] of the cells cLo-1 .. of every row (see the staging code)
+  int segEnd[9], segDelta[9];                     // flat staging: LDS slots < segEnd[q] belong to run q; sorted index = slot + segDelta[q]
+  int total, winOk;                               // staged candidates; 1 if the window covers the batch's cells
   int batchLo, batchHi, retry;                    // current batch of particles; retry: small-batch mode
 };
 
@@ -177,6 +181,9 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   // two x-rows of cells (the runs then span whole rows) or sits in very dense cells — it serves its particles in smaller
   // batches instead: at most 32 particles, never across an x-row boundary.
   const int blockHi = min(p0 + FN_PART, rangeEnd);
+  // own record and cell: issued now, needed only after the staging
+  const float4 myPos = alive ? d.sortedPos[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int myCell = alive ? (int)d.keys[id] : 0;
   if (tid == 0) { sh.batchLo = p0; sh.retry = 0; }
   while (true) {
   __syncthreads();  // (also protects the LDS of the previous batch)
@@ -194,21 +201,49 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
   __syncthreads();
   const int batchHi = sh.batchHi;
-  if (tid < 9) {
-    const int cLo = (int)d.keys[batchLo], cHi = (int)d.keys[batchHi - 1];
-    const int sy = tid % 3 - 1, sz = tid / 3 - 1;
+  // Every global round trip below is on the workgroup's critical path (two workgroups per CU cannot hide them), so the
+  // staging is three trips deep: (1) the batch's first / last cell, (2) the cell table of the 9 rows into LDS, (3) all
+  // candidate records at once, flat over the concatenated runs.
+  const int cLo = (int)d.keys[batchLo], cHi = (int)d.keys[batchHi - 1];
+  const int nc = cHi - cLo + 3;  // cells per row: cLo-1 .. cHi+1; the window holds nc+1 table entries
+  const bool winOk = nc + 1 <= FN_WIN;
+  if (tid < 9 * FN_WIN) {
+    const int r = tid / FN_WIN, i = tid % FN_WIN;
+    const int sy = r % 3 - 1, sz = r / 3 - 1;
     const int shift = sy * d.gx + sz * d.gx * d.gy;
-    const int a = max(cLo - 1 + shift, 0), b = min(cHi + 1 + shift, d.G - 1);
-    int lo = 0, hi = 0;
-    if (a <= b) { lo = (int)d.cellStart[a]; hi = (int)d.cellStart[b + 1]; }
-    sh.rowLo[tid] = lo; sh.rowHi[tid] = hi;
+    if (winOk) {
+      if (i <= nc) sh.win[r][i] = (int)d.cellStart[min(max(cLo - 1 + shift + i, 0), d.G)];
+    } else if (i < 2) {  // sparse cells: only the two ends of the run (particle_cells reads the table directly)
+      const int a = max(cLo - 1 + shift, 0), b = min(cHi + 1 + shift, d.G - 1);
+      sh.win[r][i] = (a <= b) ? (int)d.cellStart[i == 0 ? a : b + 1] : 0;
+    }
   }
-  if (tid >= 64 && tid < 96) sh.binU[tid - 64] = d.binU[tid - 64];
+  if (tid >= 192 && tid < 224) sh.binU[tid - 192] = d.binU[tid - 192];
   __syncthreads();
-  if (tid == 0 && !sh.retry) {
+  if (tid == 0) {
     int total = 0;
-    for (int r = 0; r < 9; r++) total += sh.rowHi[r] - sh.rowLo[r];
-    if (total > FN_CAND_CAP) sh.retry = 2;  // 2 = "switch now": redo this workgroup in small batches
+    for (int r = 0; r < 9; r++) {
+      const int lo = sh.win[r][0], hi = winOk ? sh.win[r][nc] : sh.win[r][1];
+      sh.rowLo[r] = lo; sh.rowHi[r] = max(hi, lo);  // (clamped table reads: an out-of-grid run is empty)
+      total += sh.rowHi[r] - lo;
+    }
+    sh.winOk = winOk ? 1 : 0;
+    if (total > FN_CAND_CAP && !sh.retry) sh.retry = 2;  // 2 = "switch now": redo this workgroup in small batches
+    else {
+      int base = 0;
+      // the own row (4) first, then the others: if LDS still runs out, the most-used runs are the ones that are staged
+      const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+      for (int q = 0; q < 9; q++) {
+        const int r = order[q];
+        int n = sh.rowHi[r] - sh.rowLo[r];
+        sh.rowBase[r] = base;
+        if (base + n > FN_CAND_CAP) { sh.rowHi[r] = sh.rowLo[r]; n = 0; atomicAdd(&d.dbg[3], 1u); }  // not staged (rare)
+        sh.segDelta[q] = sh.rowLo[r] - base;
+        base += n;
+        sh.segEnd[q] = base;
+      }
+      sh.total = base;
+    }
   }
   __syncthreads();
   if (sh.retry == 2) {  // uniform
@@ -216,25 +251,30 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     if (tid == 0) sh.retry = 1;
     continue;
   }
-  if (tid == 0) {
-    int base = 0;
-    // the own row (4) first, then the others: if LDS still runs out, the most-used runs are the ones that are staged
-    const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
-    for (int q = 0; q < 9; q++) {
-      const int r = order[q];
-      const int n = sh.rowHi[r] - sh.rowLo[r];
-      sh.rowBase[r] = base;
-      if (base + n > FN_CAND_CAP) { sh.rowHi[r] = sh.rowLo[r]; atomicAdd(&d.dbg[3], 1u); continue; }  // not staged (rare)
-      base += n;
-    }
-  }
-  __syncthreads();
+  {
+    const int total = sh.total;
+    int se[8], sd[9];
+#pragma unroll
+    for (int q = 0; q < 8; q++) se[q] = sh.segEnd[q];
+#pragma unroll
+    for (int q = 0; q < 9; q++) sd[q] = sh.segDelta[q];
+    constexpr int PER = 8;  // records per thread and round, all loads of a round in flight together
 #pragma unroll 1
-  for (int r = 0; r < 9; r++) {
-    const int lo = sh.rowLo[r], n = sh.rowHi[r] - lo, base = sh.rowBase[r];
-    for (int t = tid; t < n; t += FN_THREADS) {
-      const float4 q = d.sortedPos[lo + t];
-      sh.x[base + t] = q.x; sh.y[base + t] = q.y; sh.z[base + t] = q.z;
+    for (int f0 = 0; f0 < total; f0 += PER * FN_THREADS) {
+      float4 rec[PER];
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int f = f0 + tid + u * FN_THREADS;
+        int delta = sd[0];
+#pragma unroll
+        for (int q = 0; q < 8; q++) delta = (f >= se[q]) ? sd[q + 1] : delta;  // runs are laid out in order of q
+        if (f < total) rec[u] = d.sortedPos[f + delta];
+      }
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int f = f0 + tid + u * FN_THREADS;
+        if (f < total) { sh.x[f] = rec[u].x; sh.y[f] = rec[u].y; sh.z[f] = rec[u].z; }
+      }
     }
   }
   __syncthreads();
@@ -249,9 +289,39 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
 #pragma unroll
   for (int i = 0; i < 4; i++) { num[i] = 0; ldsLo[i] = 0; absDelta[i] = 0; }
   if (alive) {
-    me = d.sortedPos[id];
+    me = myPos;
     CellSet cs;
-    particle_cells(d, me, (int)d.keys[id], cs);
+    {  // particle_cells() with the cell table read from the LDS window where possible
+      const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
+      const float cfx = (float)(int)(me.x * d.cellSizeInv) * d.cellSize;
+      const float cfy = (float)(int)(me.y * d.cellSizeInv) * d.cellSize;
+      const float cfz = (float)(int)(me.z * d.cellSizeInv) * d.cellSize;
+      const int dx = ((px - cfx) < d.h) ? -1 : 1;
+      const int dy = ((py - cfy) < d.h) ? -1 : 1;
+      const int dz = ((pz - cfz) < d.h) ? -1 : 1;
+      const int sy = dy * d.gx, sz = dz * d.gx * d.gy;
+      const int off[8] = {0, dx, sy, sz, dx + sy, dx + sz, sy + sz, dx + sy + sz};
+      const int xs[8] = {0, dx, 0, 0, dx, dx, 0, dx};  // the x part of off[]: position inside the row's window
+      const int ry = dy + 1, rz = dz + 1;
+      const int rows[8] = {4, 4, ry + 3, 1 + 3 * rz, ry + 3, 1 + 3 * rz, ry + 3 * rz, ry + 3 * rz};
+      const bool useWin = sh.winOk != 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int raw = myCell + off[k];
+        const int c = wrap_cell(raw, d.G);
+        if (c == raw && useWin) {
+          const int i = myCell - cLo + 1 + xs[k];  // in [0, nc): the batch's cells are cLo..cHi, the window starts at cLo-1
+          cs.row[k] = rows[k];
+          cs.lo[k] = sh.win[rows[k]][i];
+          cs.hi[k] = sh.win[rows[k]][i + 1];
+        } else {  // wrapped cells (never staged: only their emptiness matters) and batches wider than the window
+          const int cc = min(max(c, 0), d.G - 1);
+          cs.row[k] = (c == raw) ? rows[k] : -1;
+          cs.lo[k] = (int)d.cellStart[cc];
+          cs.hi[k] = (int)d.cellStart[cc + 1];
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int n = cs.hi[k] - cs.lo[k];
@@ -282,23 +352,45 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   int cnt = 0;
   int segEnd[4];
   const f32x2 mx = {me.x, me.x}, my = {me.y, me.y}, mz = {me.z, me.z};
-  // one aligned quad of candidates; CHECKED quads (first / last of a cell) also test that the slot lies inside the cell
+  // The filter only has to be a superset of both reference passes (the replay below decides with the reference's exact
+  // expressions), so it may use fused multiply-adds: its d^2 differs from the reference's by < 2^-21 relative, which the
+  // 2^-20 margin on the radius absorbs. A hit is the SIGN BIT of d^2 - r^2 (two distinct floats never subtract to zero with
+  // denormals on), shifted into a per-lane bit mask with one v_alignbit per candidate; every 32 candidates, and at the end
+  // of a cell, the few set bits are turned into list entries in traversal order.
+  const float r2f = r2max * (1.f + 0x1p-20f);
+  const f32x2 thr = {r2f, r2f};
 #define FN_LOAD(a, X, Y, Z)                                                                     \
   const f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);                                    \
   const f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);                                    \
   const f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
-#define FN_TEST(a, X, Y, Z, CHECKED)                                                            \
+#define FN_TEST(X, Y, Z)                                                                        \
   {                                                                                             \
     const f32x2 ex0 = mx - X.xy, ex1 = mx - X.zw, ey0 = my - Y.xy, ey1 = my - Y.zw;             \
     const f32x2 ez0 = mz - Z.xy, ez1 = mz - Z.zw;                                               \
-    const f32x2 q0 = ex0 * ex0 + ey0 * ey0 + ez0 * ez0, q1 = ex1 * ex1 + ey1 * ey1 + ez1 * ez1; \
-    const float d2[4] = {q0.x, q0.y, q1.x, q1.y};                                               \
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                             \
-      bool hit = d2[u] <= r2max;                                                                \
-      if (CHECKED) hit = hit && ((unsigned)((a) + u - cellLo) < (unsigned)n);                   \
-      if (i == 0) hit = hit && ((a) + u != selfSlot);                                           \
-      if (hit) sh.list[min(cnt, FN_LIST_CAP - 1)][tid] = (uint16_t)((a) + u);                   \
-      cnt += hit ? 1 : 0;                                                                       \
+    const f32x2 q0 = __builtin_elementwise_fma(ez0, ez0, __builtin_elementwise_fma(ey0, ey0, ex0 * ex0)); \
+    const f32x2 q1 = __builtin_elementwise_fma(ez1, ez1, __builtin_elementwise_fma(ey1, ey1, ex1 * ex1)); \
+    const f32x2 s0 = q0 - thr, s1 = q1 - thr;                                                   \
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s0.x), 31);                            \
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s0.y), 31);                            \
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s1.x), 31);                            \
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s1.y), 31);                            \
+  }
+  // k candidates (slots aBase .. aBase+k-1, first one in the highest of the k low bits of acc) -> list entries
+#define FN_FLUSH(k)                                                                             \
+  {                                                                                             \
+    uint32_t m = ((k) == 0) ? 0u : (acc << (32 - (k)));   /* candidate t at bit 31 - t */       \
+    const int lowT = cellLo - aBase, hiT = cellHi - aBase;                                      \
+    if (lowT > 0) m &= 0xffffffffu >> lowT;               /* slots before the cell (first chunk) */ \
+    if (hiT < 32) m &= ~(0xffffffffu >> hiT);             /* slots past the cell */             \
+    if (i == 0) {                                         /* the particle itself */             \
+      const unsigned ts = (unsigned)(selfSlot - aBase);                                         \
+      if (ts < 32u) m &= ~(0x80000000u >> ts);                                                  \
+    }                                                                                           \
+    while (m != 0u) {                                                                           \
+      const int bpos = __clz((int)m);                                                           \
+      sh.list[min(cnt, FN_LIST_CAP - 1)][tid] = (uint16_t)(aBase + bpos);                       \
+      cnt++;                                                                                    \
+      m &= ~(0x80000000u >> bpos);                                                              \
     }                                                                                           \
   }
 #pragma unroll
@@ -306,28 +398,27 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     const int n = num[i], cellLo = ldsLo[i], cellHi = cellLo + n;
     if (n > 0) {
       int a = cellLo & ~3;  // aligned slot at or before the cell
-      { FN_LOAD(a, X, Y, Z) FN_TEST(a, X, Y, Z, true) }
-      a += 4;
-      if (a + 4 <= cellHi) {
-        // interior quads lie wholly inside the cell; the next quad's three LDS reads are issued before the current
-        // quad is tested (software pipelining: the wave has only one partner on its SIMD to hide LDS latency)
-        f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);
-        f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);
-        f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
-        for (; a + 8 <= cellHi; a += 4) {
-          FN_LOAD(a + 4, Xn, Yn, Zn)
-          FN_TEST(a, X, Y, Z, false)
-          X = Xn; Y = Yn; Z = Zn;
-        }
-        FN_TEST(a, X, Y, Z, false)
-        a += 4;
+      int aBase = a, k = 0;
+      uint32_t acc = 0u;
+      f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);
+      f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);
+      f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
+      while (a < cellHi) {
+        // the next quad's three LDS reads are issued before the current quad is tested (the wave has only one partner
+        // on its SIMD to hide LDS latency); they may run up to 7 slots past the cell: FN_CAND_PAD
+        FN_LOAD(a + 4, Xn, Yn, Zn)
+        FN_TEST(X, Y, Z)
+        X = Xn; Y = Yn; Z = Zn;
+        a += 4; k += 4;
+        if (k == 32) { FN_FLUSH(32) aBase = a; k = 0; }
       }
-      if (a < cellHi) { FN_LOAD(a, X, Y, Z) FN_TEST(a, X, Y, Z, true) }
+      FN_FLUSH(k)
     }
     segEnd[i] = cnt;
   }
 #undef FN_LOAD
 #undef FN_TEST
+#undef FN_FLUSH
   bool over = cnt > FN_LIST_CAP;
   const int partnerOver = __shfl_xor((int)over, 1);  // unconditional: both lanes of the pair must take part in the swap
   over = over || (partnerOver != 0);
@@ -339,25 +430,25 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
 
   // ---- 2. replay of the reference's two passes over the short lists, entirely in registers: the list (<= 48 LDS slots
-  // per lane) is expanded once into d2v[] / slotv[] with static indices, 8 entries at a time with a wave-uniform skip.
+  // per lane) is expanded once into d2v[] with static indices (the slots are re-read from LDS for the few hits that are stored), 8 entries at a time with a wave-uniform skip.
   const int total = segEnd[3];
   float d2v[FN_LIST_CAP];
-  int slotv[FN_LIST_CAP];
 #pragma unroll
   for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
     if (__any(c0 < total)) {
+      int slotv[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) slotv[c0 + u] = min((int)sh.list[c0 + u][tid], FN_CAND_CAP + FN_CAND_PAD - 1);
+      for (int u = 0; u < 8; u++) slotv[u] = min((int)sh.list[c0 + u][tid], FN_CAND_CAP + FN_CAND_PAD - 1);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int sl = slotv[c0 + u];
+        const int sl = slotv[u];
         const float ex = me.x - sh.x[sl], ey = me.y - sh.y[sl], ez = me.z - sh.z[sl];
         const float v = ex * ex + ey * ey + ez * ez;
         d2v[c0 + u] = (c0 + u < total) ? v : __builtin_inff();  // +inf never passes a `<` / `<=` test below
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < 8; u++) { d2v[c0 + u] = __builtin_inff(); slotv[c0 + u] = 0; }
+      for (int u = 0; u < 8; u++) d2v[c0 + u] = __builtin_inff();
     }
   }
   // ---- 2a. pass 0 + threshold (sphFluid.cl:157-161,310-323) without building the histogram: C(j) = number of hits in
@@ -422,7 +513,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
           rank++;
           if (pos < SPH_MAXN) {
             const int off = ((pos >> 2) << 8) + (pos & 3);  // tiled map: group stride 64 lanes * 4 slots
-            idBase[off] = slotv[e] + curDelta;
+            idBase[off] = (int)sh.list[e][tid] + curDelta;
             distBase[off] = sqrtf(d2v[e]) * d.simScale;
           }
         }
