@@ -139,7 +139,7 @@ __device__ __forceinline__ void find_neighbors_slow(const SphDev& d, int id, uin
 #define FN_CAND_CAP 4096    // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
 #endif
 #define FN_WIN 16           // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
-#define FN_CAND_PAD 8       // the aligned, prefetching 4-wide walk reads (never uses) up to 7 slots past a cell
+#define FN_CAND_PAD 12      // the aligned, prefetching 4-wide walk reads (never uses) up to 11 slots past a cell
 #ifndef FN_LIST_CAP
 #define FN_LIST_CAP 48      // compaction list entries per lane (u16 [entry][lane])
 #endif
@@ -404,12 +404,16 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
       f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);
       f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
       while (a < cellHi) {
-        // the next quad's three LDS reads are issued before the current quad is tested (the wave has only one partner
-        // on its SIMD to hide LDS latency); they may run up to 7 slots past the cell: FN_CAND_PAD
-        FN_LOAD(a + 4, Xn, Yn, Zn)
+        // two quads per trip, ping-pong: the next quad's three LDS reads are issued before the current quad is tested
+        // (the wave has only one partner on its SIMD to hide LDS latency). Reads and tests may run up to 11 slots past
+        // the cell (FN_CAND_PAD); FN_FLUSH masks those bits.
+        FN_LOAD(a + 4, Xb, Yb, Zb)
         FN_TEST(X, Y, Z)
-        X = Xn; Y = Yn; Z = Zn;
-        a += 4; k += 4;
+        X = *reinterpret_cast<const f32x4*>(&sh.x[a + 8]);
+        Y = *reinterpret_cast<const f32x4*>(&sh.y[a + 8]);
+        Z = *reinterpret_cast<const f32x4*>(&sh.z[a + 8]);
+        FN_TEST(Xb, Yb, Zb)
+        a += 8; k += 8;
         if (k == 32) { FN_FLUSH(32) aBase = a; k = 0; }
       }
       FN_FLUSH(k)
