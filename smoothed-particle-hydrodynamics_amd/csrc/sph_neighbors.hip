@@ -458,6 +458,9 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   // ---- 2a. pass 0 + threshold (sphFluid.cl:157-161,310-323) without building the histogram: C(j) = number of hits in
   // bins 0..j = number of hits with d^2 < U[j] (U precomputed exactly on the host). The reference's loop stops at
   // j* = min{ j : C(j) >= 32 } with jb = j* if C(j*) == 32, j* - 1 if it overshoots, and jb = 30 if no such j exists.
+  int liveEnd = 8;  // wave-uniform: entries at or past it are +inf in every lane, and the counting loops skip them
+#pragma unroll
+  for (int c0 = 8; c0 < FN_LIST_CAP; c0 += 8) liveEnd = __any(c0 < total) ? c0 + 8 : liveEnd;
   int lo = 0, hi = SPH_RSEG, cAtHi = 0;
 #pragma unroll 1
   for (int it = 0; it < 5; it++) {
@@ -465,7 +468,12 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     const float U = sh.binU[min(mid, SPH_RSEG - 1)];
     int c = 0;
 #pragma unroll
-    for (int e = 0; e < FN_LIST_CAP; e++) c += (d2v[e] < U) ? 1 : 0;
+    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+      if (c0 < liveEnd) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) c += (d2v[c0 + u] < U) ? 1 : 0;
+      }
+    }
     c += __shfl_xor(c, 1);
     if (lo < hi) {
       if (c >= SPH_MAXN) { hi = mid; cAtHi = c; } else lo = mid + 1;
@@ -480,7 +488,12 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   // dropped, which is what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
   unsigned long long acc = 0ull;
 #pragma unroll
-  for (int e = 0; e < FN_LIST_CAP; e++) acc |= (d2v[e] <= r2) ? (1ull << e) : 0ull;
+  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+    if (c0 < liveEnd) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc |= (d2v[c0 + u] <= r2) ? (1ull << (c0 + u)) : 0ull;
+    }
+  }
   unsigned long long below[4];  // bits of the entries before the end of cell i
 #pragma unroll
   for (int i = 0; i < 4; i++) below[i] = (segEnd[i] >= 64) ? ~0ull : ((1ull << segEnd[i]) - 1ull);
