@@ -210,23 +210,25 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
   const float4 xi = d.predPos[id];
   const NbrTile t(d, id);
-  double density = 0.0;
-#pragma unroll 2
-  for (int g = 0; g < 8; g++) {
-    const int4 j4 = t.id4(g);
-    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+  // Branch-free: all 8 id loads first, then the gathers in batches of 8 with an always-valid index (empty slots read
+  // record 0 and are masked out of the sum), so a wave keeps 8 gathers in flight instead of one per `if`.
+  int4 j4[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int jd = jj[k];
-      if (jd != -1) {
-        const float4 xj = d.predPos[jd];
-        const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
-        const float r2 = (rx * rx + ry * ry + rz * rz) * d.simScale * d.simScale;
-        if (r2 < d.hs2) {
-          const float a = d.hs2 - r2;
-          density += (double)(a * a * a);
-        }
-      }
+  for (int g = 0; g < 8; g++) j4[g] = t.id4(g);
+  double density = 0.0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int jj[8] = {j4[2 * b].x, j4[2 * b].y, j4[2 * b].z, j4[2 * b].w, j4[2 * b + 1].x, j4[2 * b + 1].y, j4[2 * b + 1].z, j4[2 * b + 1].w};
+    float4 xj[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xj[k] = d.predPos[max(jj[k], 0)];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float rx = xi.x - xj[k].x, ry = xi.y - xj[k].y, rz = xi.z - xj[k].z;
+      const float r2 = (rx * rx + ry * ry + rz * rz) * d.simScale * d.simScale;
+      const float a = d.hs2 - r2;
+      const double term = (double)(a * a * a);
+      density = (jj[k] != -1 && r2 < d.hs2) ? density + term : density;
     }
   }
   if (density < (double)d.hs6) density = (double)d.hs6;
@@ -361,26 +363,39 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   const NbrTile t(d, id);
   float rx = 0.f, ry = 0.f, rz = 0.f;
   const float hq = d.hs * 0.25f;
-#pragma unroll 2
-  for (int g = 0; g < 8; g++) {
-    const int4 j4 = t.id4(g);
-    const float4 r4 = t.dist4(g);
-    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
-    const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+  // Branch-free, like k_predict_density: map loads first, gathers in batches of PF_BATCH with an always-valid index,
+  // masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`).
+  constexpr int PF_BATCH = 8;
+  int4 j4[8];
+  float4 r4[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int jd = jj[k];
+  for (int g = 0; g < 8; g++) { j4[g] = t.id4(g); r4[g] = t.dist4(g); }
+#pragma unroll
+  for (int b = 0; b < 32 / PF_BATCH; b++) {
+    int jj[PF_BATCH];
+    float rr[PF_BATCH];
+#pragma unroll
+    for (int k = 0; k < PF_BATCH; k++) {
+      const int slot = b * PF_BATCH + k;
+      const int4 jq = j4[slot >> 2];
+      const float4 rq = r4[slot >> 2];
+      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
+      rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
+    }
+    float4 xj[PF_BATCH];
+    float rpj[PF_BATCH];
+#pragma unroll
+    for (int k = 0; k < PF_BATCH; k++) { const int jc = max(jj[k], 0); xj[k] = d.posPress[jc]; rpj[k] = d.rhoPred[jc]; }
+#pragma unroll
+    for (int k = 0; k < PF_BATCH; k++) {
       const float r = rr[k];
-      if (jd != -1 && r < d.hs) {
-        const float4 xj = d.posPress[jd];  // (x, y, z, pressure_j)
-        const float rpj = d.rhoPred[jd];
-        float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj.w) / rpj;
-        const float vx = (xi.x - xj.x) * d.simScale, vy = (xi.y - xj.y) * d.simScale, vz = (xi.z - xj.z) * d.simScale;
-        if ((double)r < d.closeR) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj;
-        rx += value * vx / r;
-        ry += value * vy / r;
-        rz += value * vz / r;
-      }
+      float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj[k].w) / rpj[k];
+      const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
+      if ((double)r < d.closeR) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj[k];
+      const bool use = jj[k] != -1 && r < d.hs;
+      rx = use ? rx + value * vx / r : rx;
+      ry = use ? ry + value * vy / r : ry;
+      rz = use ? rz + value * vz / r : rz;
     }
   }
   const float scale = (float)(d.massGradW / (double)d.rhoPred[id]);
