@@ -226,6 +226,11 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
     volatile float halfHs = hs / 2;
     d.massMu = massMu; d.hs = hs; d.hs2 = hs2; d.hs6 = hs6; d.posTimeStep = pts; d.rho0delta = r0d;
     d.closeR = 0.5 * (double)halfHs;
+    // (double)r < closeR  <=>  r < closeRf, with closeRf the smallest float whose double value is >= closeR
+    float f = (float)d.closeR;
+    while ((double)f < d.closeR) f = nextafterf(f, INFINITY);
+    while ((double)nextafterf(f, -INFINITY) >= d.closeR) f = nextafterf(f, -INFINITY);
+    d.closeRf = f;
   }
   d.massWpoly6 = ((double)cfg->mass) * cfg->Wpoly6Coefficient;
   d.massGradW = ((double)cfg->mass) * cfg->gradWspikyCoefficient;

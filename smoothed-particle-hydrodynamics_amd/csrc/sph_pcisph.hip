@@ -9,6 +9,17 @@
 
 #define TYPE_OF(p4) ((int)(p4).w)
 
+// neighbour gathers kept in flight per lane by the branch-free kernels (A/B on MI355X, config #2)
+#ifndef FC_BATCH
+#define FC_BATCH 8   // forces: two 16-B gathers per neighbour
+#endif
+#ifndef PF_BATCH
+#define PF_BATCH 8   // pressure force: 16 B + 4 B per neighbour
+#endif
+#ifndef PD_BATCH
+#define PD_BATCH 16  // predicted density: 16 B per neighbour
+#endif
+
 // the 8 x (int4 ids, float4 dists) of particle `id`
 struct NbrTile {
   const int4* ids;
@@ -118,31 +129,45 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
   float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
   uint32_t bnd = 0u, ela = 0u;  // which neighbour slots hold boundary / elastic particles: saves integrate and the
                                 // membrane kernel 32 type gathers per particle
-#pragma unroll 2
-  for (int g = 0; g < 8; g++) {
-    const int4 j4 = t.id4(g);
-    const float4 r4 = t.dist4(g);
-    const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
-    const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+  // Branch-free (see k_predict_density): map loads first, both gathers of FC_BATCH neighbours in flight together.
+  int4 j4[8];
+  float4 r4[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int jd = jj[k];
-      if (jd != -1) {
-        const float4 xj = d.sortedPos[jd];
-        if (TYPE_OF(xj) == SPH_BOUNDARY_PARTICLE) bnd |= 1u << (g * 4 + k);
-        if (TYPE_OF(xj) == SPH_ELASTIC_PARTICLE) ela |= 1u << (g * 4 + k);
-        if (rr[k] < d.hs) {
-          const float4 vj = d.velRho[jd];      // (v.xyz, rho); for a boundary neighbour v is its wall normal (sphFluid.cl:653)
-          const float rj = vj.w;
-          const float w = d.hs - rr[k];
-          sx += (vj.x - vi.x) * w / rj;
-          sy += (vj.y - vi.y) * w / rj;
-          sz += (vj.z - vi.z) * w / rj;
-          tx += d.surfTens * (xi.x - xj.x);
-          ty += d.surfTens * (xi.y - xj.y);
-          tz += d.surfTens * (xi.z - xj.z);
-        }
-      }
+  for (int g = 0; g < 8; g++) { j4[g] = t.id4(g); r4[g] = t.dist4(g); }
+#pragma unroll
+  for (int b = 0; b < 32 / FC_BATCH; b++) {
+    int jj[FC_BATCH];
+    float rr[FC_BATCH];
+#pragma unroll
+    for (int k = 0; k < FC_BATCH; k++) {
+      const int slot = b * FC_BATCH + k;
+      const int4 jq = j4[slot >> 2];
+      const float4 rq = r4[slot >> 2];
+      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
+      rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
+    }
+    float4 xj[FC_BATCH], vj[FC_BATCH];
+#pragma unroll
+    for (int k = 0; k < FC_BATCH; k++) {
+      const int jc = max(jj[k], 0);
+      xj[k] = d.sortedPos[jc];
+      vj[k] = d.velRho[jc];  // (v.xyz, rho); for a boundary neighbour v is its wall normal (sphFluid.cl:653)
+    }
+#pragma unroll
+    for (int k = 0; k < FC_BATCH; k++) {
+      const int slot = b * FC_BATCH + k;
+      const bool valid = jj[k] != -1;
+      if (valid && TYPE_OF(xj[k]) == SPH_BOUNDARY_PARTICLE) bnd |= 1u << slot;
+      if (valid && TYPE_OF(xj[k]) == SPH_ELASTIC_PARTICLE) ela |= 1u << slot;
+      const bool use = valid && rr[k] < d.hs;
+      const float rj = vj[k].w;
+      const float w = d.hs - rr[k];
+      sx = use ? sx + (vj[k].x - vi.x) * w / rj : sx;
+      sy = use ? sy + (vj[k].y - vi.y) * w / rj : sy;
+      sz = use ? sz + (vj[k].z - vi.z) * w / rj : sz;
+      tx = use ? tx + d.surfTens * (xi.x - xj[k].x) : tx;
+      ty = use ? ty + d.surfTens * (xi.y - xj[k].y) : ty;
+      tz = use ? tz + d.surfTens * (xi.z - xj[k].z) : tz;
     }
   }
   d.bndMask[id] = bnd;
@@ -217,13 +242,19 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   for (int g = 0; g < 8; g++) j4[g] = t.id4(g);
   double density = 0.0;
 #pragma unroll
-  for (int b = 0; b < 4; b++) {
-    const int jj[8] = {j4[2 * b].x, j4[2 * b].y, j4[2 * b].z, j4[2 * b].w, j4[2 * b + 1].x, j4[2 * b + 1].y, j4[2 * b + 1].z, j4[2 * b + 1].w};
-    float4 xj[8];
+  for (int b = 0; b < 32 / PD_BATCH; b++) {
+    int jj[PD_BATCH];
 #pragma unroll
-    for (int k = 0; k < 8; k++) xj[k] = d.predPos[max(jj[k], 0)];
+    for (int k = 0; k < PD_BATCH; k++) {
+      const int slot = b * PD_BATCH + k;
+      const int4 jq = j4[slot >> 2];
+      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
+    }
+    float4 xj[PD_BATCH];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < PD_BATCH; k++) xj[k] = d.predPos[max(jj[k], 0)];
+#pragma unroll
+    for (int k = 0; k < PD_BATCH; k++) {
       const float rx = xi.x - xj[k].x, ry = xi.y - xj[k].y, rz = xi.z - xj[k].z;
       const float r2 = (rx * rx + ry * ry + rz * rz) * d.simScale * d.simScale;
       const float a = d.hs2 - r2;
@@ -365,7 +396,6 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   const float hq = d.hs * 0.25f;
   // Branch-free, like k_predict_density: map loads first, gathers in batches of PF_BATCH with an always-valid index,
   // masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`).
-  constexpr int PF_BATCH = 8;
   int4 j4[8];
   float4 r4[8];
 #pragma unroll
@@ -391,7 +421,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
       const float r = rr[k];
       float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj[k].w) / rpj[k];
       const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
-      if ((double)r < d.closeR) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj[k];
+      if (r < d.closeRf) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj[k];
       const bool use = jj[k] != -1 && r < d.hs;
       rx = use ? rx + value * vx / r : rx;
       ry = use ? ry + value * vy / r : ry;
