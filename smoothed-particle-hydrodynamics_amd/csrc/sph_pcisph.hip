@@ -419,9 +419,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const float r = rr[k];
-      float value = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj[k].w) / rpj[k];
+      // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
+      // the numerator is selected first, so only one IEEE division is spent
+      const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj[k].w);
+      const float value = num / rpj[k];
       const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
-      if (r < d.closeRf) value = -(hq - r) * (hq - r) * 0.5f * d.rho0delta / rpj[k];
       const bool use = jj[k] != -1 && r < d.hs;
       rx = use ? rx + value * vx / r : rx;
       ry = use ? ry + value * vy / r : ry;
