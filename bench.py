@@ -32,6 +32,7 @@ WORKLOADS = {
     "tiny": ((8.0, 8.0, 8.0), (12, 10, 12), 0xffff),
     "cube_4M": ((80.0, 80.0, 80.0), (160, 160, 160), 0xffffffff),
     "config4_16M_box": ((78.0, 50.0, 470.0), (160, 100, 1000), 0xffffffff),  # SURVEY 8(d) config #4, strong scaling
+    "config5_64M_dambreak": ((240.0, 200.0, 310.0), (250, 400, 640), 0xffffffff),  # liquid column at low x
 }
 
 
