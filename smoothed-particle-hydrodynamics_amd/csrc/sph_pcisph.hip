@@ -52,37 +52,51 @@ __device__ __forceinline__ int xcd_block(int nblocks) {
 // A/B on MI355X (bench.py roofline, 16.5 M particles): XCD-remapped blocks + plain loads 0.66 of 8 TB/s, plain block
 // order 0.67-0.69, plain order + non-temporal loads 0.75 (6.0 TB/s = 96 % of this part's 6.29 TB/s copy rate). The pass has
 // no reuse, so neither an XCD-local L2 nor keeping the stream in cache helps.
+#ifndef DENSITY_ITEMS
+#define DENSITY_ITEMS 1   // particles per thread, all of their 8 x 16-B loads in flight together (A/B in profiles/README.md)
+#endif
 __global__ __launch_bounds__(SPH_BLOCK) void k_density(SphDev d, int nblocks) {
-  int id;
-  if (!sph_range_id(d, blockIdx.x * SPH_BLOCK + threadIdx.x, id)) return;
-  const NbrTile t(d, id);
   typedef float nt4 __attribute__((ext_vector_type(4)));
-  float4 r[8];
+  const int begin = (int)d.cellStart[d.rangeLo], end = (int)d.cellStart[d.rangeHi];
+  const int first = begin + blockIdx.x * (SPH_BLOCK * DENSITY_ITEMS) + threadIdx.x;
+  float4 r[DENSITY_ITEMS][8];
 #pragma unroll
-  for (int g = 0; g < 8; g++) {  // all 8 loads in flight before the first use
-    const nt4 q = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(&t.dist[(size_t)g * 64]));
-    r[g] = make_float4(q.x, q.y, q.z, q.w);
-  }
-  double density = 0.0;
+  for (int it = 0; it < DENSITY_ITEMS; it++) {
+    const int id = first + it * SPH_BLOCK;
+    if (id < end) {
+      const NbrTile t(d, id);
 #pragma unroll
-  for (int g = 0; g < 8; g++) {
-    const float rr[4] = {r[g].x, r[g].y, r[g].z, r[g].w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (rr[k] != -1.f) {
-        const float r2 = rr[k] * rr[k];
-        const float a = d.hs2 - r2;
-        density += (double)(a * a * a);  // no r < hScaled test here
+      for (int g = 0; g < 8; g++) {  // all loads in flight before the first use
+        const nt4 q = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(&t.dist[(size_t)g * 64]));
+        r[it][g] = make_float4(q.x, q.y, q.z, q.w);
       }
     }
   }
-  if (density < (double)d.hs6) density = (double)d.hs6;
-  density *= d.massWpoly6;
-  d.rho[id] = (float)density;
+#pragma unroll
+  for (int it = 0; it < DENSITY_ITEMS; it++) {
+    const int id = first + it * SPH_BLOCK;
+    if (id >= end) continue;
+    double density = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      const float rr[4] = {r[it][g].x, r[it][g].y, r[it][g].z, r[it][g].w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (rr[k] != -1.f) {
+          const float r2 = rr[k] * rr[k];
+          const float a = d.hs2 - r2;
+          density += (double)(a * a * a);  // no r < hScaled test here
+        }
+      }
+    }
+    if (density < (double)d.hs6) density = (double)d.hs6;
+    density *= d.massWpoly6;
+    d.rho[id] = (float)density;
+  }
 }
 
 int sphk_density(sph_solver* s, int ghostDepth) {
-  const int nb = sph_blocks(s->d.N);
+  const int nb = sph_blocks(s->d.N, SPH_BLOCK * DENSITY_ITEMS);
   hipLaunchKernelGGL(k_density, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, sph_ranged(s, ghostDepth), nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;

@@ -153,6 +153,24 @@ def test_staged_and_fused_paths_agree():
     assert scenes.bits_equal(a.getParticleIndex_cpp(), b.getParticleIndex_cpp())
 
 
+def test_viewer_frame_feed_matches_oracle():
+    """density per ORIGINAL particle through the viewer's inverse-permutation contract
+    (getDensity_cpp is in sorted order, owWorldSimulation.cpp:112-127) equals the oracle's."""
+    from sphmi import frames
+    sc = scenes.SCENES["tiny_jitter"]()
+    sim = sphmi.owPhysicsFluidSimulator(sc["cfg"], sc["position"], sc["velocity"])
+    ora = scenes.oracle_for(sc)
+    for _ in range(3):
+        sim.simulationStep(); ora.step()
+    pos, rho = frames.frame(sim)
+    N = sc["cfg"].particleCount
+    opi = ora.buffer("particleIndex").reshape(-1, 2)[:N]
+    want = ora.buffer("rho")[:N][frames.invert_particle_index(opi)]
+    assert scenes.bits_equal(rho, want)
+    assert scenes.bits_equal(pos, ora.buffer("position").reshape(-1, 4)[:N])
+    ora.close()
+
+
 def _check_search_structures(hip, cfg, N):
     """Size-independent properties of the binning outputs."""
     pi = hip.read_particleIndex_buffer()

@@ -163,3 +163,33 @@ def test_config_struct_layout_matches_header():
         size, off = map(int, subprocess.check_output([exe]).split())
     assert ctypes.sizeof(sphmi.SphConfig) == size
     assert sphmi.SphConfig.stream.offset == off
+
+
+def test_frame_feed_inversion_and_writers(tmp_path):
+    """the viewer's inverse-permutation contract and the headless frame writers (no GPU needed)."""
+    from sphmi import frames
+    rng = np.random.default_rng(5)
+    n = 1000
+    perm = rng.permutation(n).astype(np.uint32)            # sorted position -> orig id
+    pi = np.stack([np.sort(rng.integers(0, 50, n)).astype(np.uint32), perm], axis=1)
+    back = frames.invert_particle_index(pi)
+    # the reference's loop: p_indexb[2*p_indexb[2*i+1]+0] = i  (owWorldSimulation.cpp:112-116)
+    ref = np.empty(n, np.uint32)
+    for i in range(n):
+        ref[pi[i, 1]] = i
+    assert np.array_equal(back, ref)
+    pos = rng.random((n, 4)).astype(np.float32)
+    pos[:, 3] = np.where(np.arange(n) % 3 == 0, np.float32(3.1), np.float32(1.1))
+    rho = (1000 + 60 * rng.random(n)).astype(np.float32)
+    kept = frames.write_vtk(tmp_path / "f.vtk", pos, rho)
+    assert kept == int((pos[:, 3].astype(np.int32) != 3).sum())
+    raw = open(tmp_path / "f.vtk", "rb").read()
+    off = raw.index(b"POINTS") + len(("POINTS %d float\n" % kept).encode())
+    xyz = np.frombuffer(raw[off:off + 12 * kept], ">f4").reshape(-1, 3)
+    assert np.array_equal(xyz.astype(np.float32), pos[pos[:, 3].astype(np.int32) != 3][:, :3])
+    frames.write_npz(tmp_path / "f.npz", pos, rho, step=7)
+    z = np.load(tmp_path / "f.npz")
+    assert np.array_equal(z["position"], pos) and np.array_equal(z["density"], rho) and int(z["step"]) == 7
+    rgb = frames.density_colour(np.float32([990, 1005, 1015, 1025, 1035, 1100]), 1000.0)
+    assert np.allclose(rgb[0], (0, 0, 1)) and np.allclose(rgb[1], (0, 0.5, 1)) and np.allclose(rgb[2], (0, 1, 0.5))
+    assert np.allclose(rgb[3], (0.5, 1, 0)) and np.allclose(rgb[4], (1, 0.5, 0)) and np.allclose(rgb[5], (1, 0, 0))

@@ -8,12 +8,18 @@ import scenes  # noqa: E402
 WORK = {"1M": ((50.0, 50.0, 50.0), (100, 100, 100), 0xffff), "4M": ((80.0, 80.0, 80.0), (160, 160, 160), 0xffffffff),
         "8M": ((100.0, 100.0, 100.0), (200, 200, 200), 0xffffffff),
         "16M": ((78.0, 50.0, 470.0), (160, 100, 1000), 0xffffffff)}
-name = sys.argv[1] if len(sys.argv) > 1 else "1M"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-box, lat, mask = WORK[name]
-sc = scenes.liquid_box(box, lat, mask=mask)
-h = scenes.hip_for(sc)
-for it in range(steps):
-    h.step(it)
-h.synchronize()
-print("done", name, sc["cfg"].particleCount, steps)
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "1M"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    box, lat, mask = WORK[name]
+    sc = scenes.liquid_box(box, lat, mask=mask)
+    h = scenes.hip_for(sc)
+    for it in range(steps):
+        h.step(it)
+    h.synchronize()
+    print("done", name, sc["cfg"].particleCount, steps)
+
+
+if __name__ == "__main__":
+    main()
