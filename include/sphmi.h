@@ -153,9 +153,12 @@ typedef struct sph_slab {
 #define SPH_SLAB_RECORD_WORDS 9
 int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t* globalIds /* host, particleCount entries */);
 /* counts[0] = authoritative particles kept, counts[1] / counts[2] = records written to msgDown / msgUp (each has room for
- * `capRecords`). Blocking (the counts come back to the host). */
+ * `capRecords`), every list in ascending global-id order (order-preserving compaction of the sorted local set).
+ * Blocking (the counts come back to the host). */
 int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t capRecords, int32_t counts[3]);
-/* New local set = kept + nDown records received from below + nUp from above, sorted by global id. */
+/* New local set = kept + nDown records received from below + nUp from above, sorted by global id (three-way merge: the
+ * received messages must be in ascending global-id order, as sph_slab_pack writes them; a message that is not makes the
+ * next sph_slab_pack fail with SPH_ERR_INVALID). */
 int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp);
 int sph_particle_count(sph_solver* s);
 /* Blocking read of the local set in its current order: positions, velocities (4 floats each), global ids and the

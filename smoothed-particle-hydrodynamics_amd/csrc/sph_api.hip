@@ -624,7 +624,8 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
   SPH_HIP(hipMemcpyAsync(s->d.sortedPos, s->d.posOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
   SPH_HIP(hipMemcpyAsync(s->d.sortedVel, s->d.velOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
   SPH_HIP(hipMemcpyAsync(s->d.keys, s->d.gid, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
-  int rc = sphk_slab_rebuild(s, nullptr, 0, nullptr, 0, s->d.N);
+  SPH_HIP(hipMemsetAsync(s->slabCounts, 0, sizeof(uint32_t) * 4, s->stream));
+  int rc = sphk_slab_sort_rebuild(s, s->d.N);
   if (rc != SPH_OK) return rc;
   SPH_HIP(hipStreamSynchronize(s->stream));
   return SPH_OK;
@@ -640,6 +641,11 @@ extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t 
   SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
   SPH_HIP(hipStreamSynchronize(s->stream));
   counts[0] = (int32_t)h[0]; counts[1] = (int32_t)h[1]; counts[2] = (int32_t)h[2];
+  if (h[3]) {  // raised by the last rebuild's merge kernels
+    SPH_HIP(hipMemsetAsync(s->slabCounts + 3, 0, sizeof(uint32_t), s->stream));
+    sph_set_error("a halo message passed to the last sph_slab_rebuild was not sorted by global id");
+    return SPH_ERR_INVALID;
+  }
   s->slabKept = (int)h[0];
   if ((int)h[1] > capRecords || (int)h[2] > capRecords) { sph_set_error("halo message overflow: %u / %u records, room for %d", h[1], h[2], capRecords); return SPH_ERR_SIZE; }
   return SPH_OK;

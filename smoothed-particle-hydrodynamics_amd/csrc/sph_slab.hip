@@ -15,60 +15,109 @@ __device__ __forceinline__ void put_record(uint32_t* msg, uint32_t j, const floa
 
 // Owned particles (flag set at the last rebuild) are the authoritative ones. All of them stay in the local set (they move
 // less than one cell layer per step); those now within W layers of a cut are also copied into the neighbour's message.
-// Order is irrelevant here (the rebuild sorts by global id), so slots are handed out by counters: LDS counters inside a
-// workgroup of 2048 particles, then ONE global atomic per workgroup and destination (a single hot word serves only
-// ~88 atomics/us on this part: one atomic per wave cost 0.19 ms per step at 1 M particles).
+// The compaction is ORDER-PRESERVING: the local arrays are sorted by global id, so the kept set and both messages come
+// out sorted by global id and the receiver can rebuild with a three-way merge instead of a sort. Three launches:
+//   k_slab_pack<false>  per workgroup of 2048 particles, how many go to each of the three destinations
+//   k_slab_scan         exclusive scan of those counts over the workgroups (one workgroup) + the three totals
+//   k_slab_pack<true>   the same flags again, slot = workgroup offset + rank inside the workgroup (ballot prefixes)
 #define PACK_ITEMS 8
-__global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab, uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ msgDown, uint32_t* __restrict__ msgUp,
-                                                         int capRecords) {
-  __shared__ uint32_t local[3], base[3];
-  if (threadIdx.x < 3) local[threadIdx.x] = 0u;
-  __syncthreads();
-  const int first = blockIdx.x * (SPH_BLOCK * PACK_ITEMS) + threadIdx.x;
-  uint32_t slotKeep[PACK_ITEMS], slotDown[PACK_ITEMS], slotUp[PACK_ITEMS];
+#define PACK_SPAN (SPH_BLOCK * PACK_ITEMS)
+
+template <bool WRITE>
+__global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab, uint32_t* __restrict__ blockCounts,
+                                                         const uint32_t* __restrict__ blockOffsets, uint32_t* __restrict__ msgDown,
+                                                         uint32_t* __restrict__ msgUp, int capRecords) {
+  __shared__ uint32_t tot[PACK_ITEMS * (SPH_BLOCK / 64)][3];  // hits per (round, wave), then their exclusive prefix
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int first = blockIdx.x * PACK_SPAN + tid;
+  uint32_t flags[PACK_ITEMS], rank[PACK_ITEMS];  // bit c: goes to destination c; 10 bits of rank per destination
 #pragma unroll
-  for (int u = 0; u < PACK_ITEMS; u++) {
+  for (int u = 0; u < PACK_ITEMS; u++) {  // element order inside the workgroup: (round u, thread) = ascending particle index
     const int i = first + u * SPH_BLOCK;
-    slotKeep[u] = slotDown[u] = slotUp[u] = 0xffffffffu;
+    uint32_t f = 0u;
     if (i < d.N && d.owned[i]) {
       const int layer = (int)(d.posOrig[i].z * d.cellSizeInv);  // the z cell coordinate hashParticles uses (sphFluid.cl:199)
-      slotKeep[u] = atomicAdd(&local[0], 1u);
-      if (slab.hasLower && layer < slab.layerLo + slab.ghostLayers) slotDown[u] = atomicAdd(&local[1], 1u);
-      if (slab.hasUpper && layer >= slab.layerHi - slab.ghostLayers) slotUp[u] = atomicAdd(&local[2], 1u);
+      f = 1u;
+      if (slab.hasLower && layer < slab.layerLo + slab.ghostLayers) f |= 2u;
+      if (slab.hasUpper && layer >= slab.layerHi - slab.ghostLayers) f |= 4u;
     }
+    flags[u] = f;
+    uint32_t r = 0u;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const unsigned long long b = __ballot((f >> c) & 1u);
+      r |= (uint32_t)__popcll(b & lt) << (10 * c);
+      if (lane == 0) tot[u * (SPH_BLOCK / 64) + wave][c] = (uint32_t)__popcll(b);
+    }
+    rank[u] = r;
   }
   __syncthreads();
-  if (threadIdx.x < 3) base[threadIdx.x] = local[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], local[threadIdx.x]) : 0u;
+  if (tid < 3) {  // exclusive prefix over the 32 (round, wave) groups; the block total goes out in counting mode
+    uint32_t run = 0u;
+    for (int g = 0; g < PACK_ITEMS * (SPH_BLOCK / 64); g++) { const uint32_t v = tot[g][tid]; tot[g][tid] = run; run += v; }
+    if (!WRITE) blockCounts[(size_t)blockIdx.x * 4 + tid] = run;
+  }
+  if (!WRITE) return;
   __syncthreads();
+  const uint32_t base0 = blockOffsets[(size_t)blockIdx.x * 4 + 0], base1 = blockOffsets[(size_t)blockIdx.x * 4 + 1],
+                 base2 = blockOffsets[(size_t)blockIdx.x * 4 + 2];
 #pragma unroll
   for (int u = 0; u < PACK_ITEMS; u++) {
-    if (slotKeep[u] == 0xffffffffu) continue;
+    const uint32_t f = flags[u];
+    if (!(f & 1u)) continue;
     const int i = first + u * SPH_BLOCK;
+    const int g = u * (SPH_BLOCK / 64) + wave;
     const float4 p = d.posOrig[i], v = d.velOrig[i];
-    const uint32_t g = d.gid[i];
-    const uint32_t k = base[0] + slotKeep[u];
-    d.sortedPos[k] = p; d.sortedVel[k] = v; d.keys[k] = g;  // sorted* / keys are free between two steps: staging area
-    if (slotDown[u] != 0xffffffffu && (int)(base[1] + slotDown[u]) < capRecords) put_record(msgDown, base[1] + slotDown[u], p, v, g);
-    if (slotUp[u] != 0xffffffffu && (int)(base[2] + slotUp[u]) < capRecords) put_record(msgUp, base[2] + slotUp[u], p, v, g);
+    const uint32_t gid = d.gid[i];
+    const uint32_t k = base0 + tot[g][0] + (rank[u] & 1023u);
+    d.sortedPos[k] = p; d.sortedVel[k] = v; d.keys[k] = gid;  // sorted* / keys are free between two steps: staging area
+    if (f & 2u) { const uint32_t j = base1 + tot[g][1] + ((rank[u] >> 10) & 1023u); if ((int)j < capRecords) put_record(msgDown, j, p, v, gid); }
+    if (f & 4u) { const uint32_t j = base2 + tot[g][2] + ((rank[u] >> 20) & 1023u); if ((int)j < capRecords) put_record(msgUp, j, p, v, gid); }
   }
+}
+
+// blockOffsets[b][c] = sum of blockCounts[b'][c] over b' < b; counts[c] = grand totals. One workgroup, 256 blocks per trip.
+__global__ __launch_bounds__(SPH_BLOCK) void k_slab_scan(const uint32_t* __restrict__ blockCounts, uint32_t* __restrict__ blockOffsets,
+                                                         int nb, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t buf[SPH_BLOCK][3];
+  __shared__ uint32_t carry[3];
+  const int tid = threadIdx.x;
+  if (tid < 3) carry[tid] = 0u;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += SPH_BLOCK) {
+    const int b = b0 + tid;
+    uint32_t v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { v[c] = (b < nb) ? blockCounts[(size_t)b * 4 + c] : 0u; buf[tid][c] = v[c]; }
+    __syncthreads();
+    for (int off = 1; off < SPH_BLOCK; off <<= 1) {  // inclusive Hillis-Steele scan of the three columns
+      uint32_t add[3] = {0u, 0u, 0u};
+      if (tid >= off) { add[0] = buf[tid - off][0]; add[1] = buf[tid - off][1]; add[2] = buf[tid - off][2]; }
+      __syncthreads();
+      buf[tid][0] += add[0]; buf[tid][1] += add[1]; buf[tid][2] += add[2];
+      __syncthreads();
+    }
+    if (b < nb) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) blockOffsets[(size_t)b * 4 + c] = carry[c] + buf[tid][c] - v[c];
+    }
+    __syncthreads();
+    if (tid < 3) carry[tid] += buf[SPH_BLOCK - 1][tid];
+    __syncthreads();
+  }
+  if (tid < 3) counts[tid] = carry[tid];
 }
 
 int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords) {
-  SPH_HIP(hipMemsetAsync(s->slabCounts, 0, sizeof(uint32_t) * 4, s->stream));
-  hipLaunchKernelGGL(k_slab_pack, dim3(sph_blocks(s->d.N, SPH_BLOCK * PACK_ITEMS)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab,
-                     s->slabCounts, msgDown, msgUp, capRecords);
+  const int nb = sph_blocks(s->d.N, PACK_SPAN);
+  uint32_t* blockCounts = s->blockHist;  // the radix-sort workspace is idle between two steps: >= capacity/16 words
+  uint32_t* blockOffsets = s->blockHist + (size_t)nb * 4;
+  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords);
+  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, s->slabCounts);
+  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
-}
-
-__global__ __launch_bounds__(SPH_BLOCK) void k_slab_append(SphDev d, const uint32_t* __restrict__ msg, int n, int base) {
-  const int t = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t* r = msg + (size_t)t * REC;
-  d.sortedPos[base + t] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
-  d.sortedVel[base + t] = make_float4(__uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]));
-  d.keys[base + t] = r[8];
 }
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_iota(uint32_t* __restrict__ v, int n) {
@@ -89,11 +138,62 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_gather(SphDev d, sph_slab sl
   d.owned[i] = (layer >= slab.layerLo && layer < slab.layerHi) ? 1u : 0u;
 }
 
-// staging area already holds `kept` records (from k_slab_pack or sph_slab_init)
+// ---- rebuild by three-way merge. The kept set (staging: sortedPos / sortedVel / keys) and both received messages are
+// sorted by global id and global ids are unique, so the final index of an element is its own index plus the number of
+// smaller ids in the other two lists (two binary searches). A message that is not sorted raises slabCounts[3], which the
+// next sph_slab_pack reports as an error.
+__device__ __forceinline__ int lower_bound_keys(const uint32_t* __restrict__ keys, int n, uint32_t g) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < g) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int lower_bound_msg(const uint32_t* __restrict__ msg, int n, uint32_t g) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (msg[(size_t)mid * REC + 8] < g) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ void place_particle(const SphDev& d, const sph_slab& slab, int at, const float4 p, const float4 v, uint32_t g) {
+  d.posOrig[at] = p;
+  d.velOrig[at] = v;
+  d.gid[at] = g;
+  const int layer = (int)(p.z * d.cellSizeInv);
+  d.owned[at] = (layer >= slab.layerLo && layer < slab.layerHi) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_kept(SphDev d, sph_slab slab, int kept, const uint32_t* __restrict__ recvDown,
+                                                               int nDown, const uint32_t* __restrict__ recvUp, int nUp) {
+  const int i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (i >= kept) return;
+  const uint32_t g = d.keys[i];
+  const int at = i + lower_bound_msg(recvDown, nDown, g) + lower_bound_msg(recvUp, nUp, g);
+  place_particle(d, slab, at, d.sortedPos[i], d.sortedVel[i], g);
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_msg(SphDev d, sph_slab slab, int kept, const uint32_t* __restrict__ msg, int n,
+                                                              const uint32_t* __restrict__ other, int nOther, uint32_t* __restrict__ unsorted) {
+  const int j = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t* r = msg + (size_t)j * REC;
+  const uint32_t g = r[8];
+  if (j > 0 && msg[(size_t)(j - 1) * REC + 8] >= g) atomicOr(unsorted, 1u);
+  const int at = j + lower_bound_keys(d.keys, kept, g) + lower_bound_msg(other, nOther, g);
+  place_particle(d, slab, at, make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])),
+                 make_float4(__uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7])), g);
+}
+
 int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept) {
   const int total = kept + nDown + nUp;
-  if (nDown) hipLaunchKernelGGL(k_slab_append, dim3(sph_blocks(nDown)), dim3(SPH_BLOCK), 0, s->stream, s->d, recvDown, nDown, kept);
-  if (nUp) hipLaunchKernelGGL(k_slab_append, dim3(sph_blocks(nUp)), dim3(SPH_BLOCK), 0, s->stream, s->d, recvUp, nUp, kept + nDown);
+  if (kept) hipLaunchKernelGGL(k_slab_merge_kept, dim3(sph_blocks(kept)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvDown, nDown, recvUp, nUp);
+  if (nDown) hipLaunchKernelGGL(k_slab_merge_msg, dim3(sph_blocks(nDown)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvDown, nDown, recvUp, nUp, s->slabCounts + 3);
+  if (nUp) hipLaunchKernelGGL(k_slab_merge_msg, dim3(sph_blocks(nUp)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvUp, nUp, recvDown, nDown, s->slabCounts + 3);
+  SPH_HIP(hipGetLastError());
+  s->d.N = total;
+  s->progress = 0;
+  return SPH_OK;
+}
+
+// Initial set in any order (sph_slab_init): staging area holds n records; sort them by global id.
+int sphk_slab_sort_rebuild(sph_solver* s, int total) {
   hipLaunchKernelGGL(k_iota, dim3(sph_blocks(total)), dim3(SPH_BLOCK), 0, s->stream, s->d.vals, total);
   int rc = sphk_sort_pairs(s, total, s->slab.globalIdBits);  // stable LSD radix sort by global id (keys), vals follow
   if (rc != SPH_OK) return rc;

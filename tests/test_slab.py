@@ -116,3 +116,42 @@ def test_single_rank_slab_backend_equals_plain_solver():
     assert np.array_equal(gid, np.arange(n))
     assert scenes.bits_equal(pos, plain.read_position_buffer())
     assert scenes.bits_equal(vel, plain.read_velocity_buffer())
+
+
+@pytest.mark.gpu
+def test_initial_ids_in_any_order_and_unsorted_message_is_rejected():
+    """sph_slab_init sorts an arbitrary initial order by global id; the per-step rebuild is a three-way merge and needs
+    messages in ascending global-id order (as sph_slab_pack writes them): an unsorted one must fail loudly."""
+    import torch
+    import sphmi
+    sc = scenes.liquid_box((8.0, 8.0, 20.0), (12, 10, 30), mask=0xffffffff, jitter_in_r0=0.05)
+    cfg = sc["cfg"]
+    n = cfg.particleCount
+    lay = S.particle_layers(sc["position"], cfg)
+    lo, hi = int(lay.min()), int(lay.max()) + 1
+    mid = (lo + hi) // 2
+    slab = S.make_slab([lo, mid, hi], 0, 2, n)  # rank 0 of 2: has an upper neighbour
+    idx = S.local_indices(lay, slab)
+    perm = np.random.default_rng(3).permutation(idx.size)
+    be = S.HipSlabBackend(cfg, sc["position"][idx][perm], sc["velocity"][idx][perm], idx[perm], slab)
+    pos, vel, gid, owned = be.solver.slab_read()
+    assert np.array_equal(gid, idx) and scenes.bits_equal(pos, sc["position"][idx])
+    be.step(0)
+    kept, down, up = be.pack()
+    assert down.numel() == 0 and up.numel() > 0
+    rec = up.cpu().numpy().view(np.uint32).reshape(-1, S.SLAB_RECORD_WORDS if hasattr(S, "SLAB_RECORD_WORDS") else 9)
+    assert np.all(np.diff(rec[:, 8].astype(np.int64)) > 0)            # messages leave sorted by global id
+    # a well-formed message from "above": the ghost particles this rank would receive = its own non-owned ones, sorted
+    ghosts = np.flatnonzero(owned == 0)
+    msg = np.zeros((ghosts.size, 9), np.uint32)
+    msg[:, 0:4] = pos[ghosts].view(np.uint32); msg[:, 4:8] = vel[ghosts].view(np.uint32); msg[:, 8] = gid[ghosts]
+    good = torch.from_numpy(msg.view(np.int32).reshape(-1)).to(be.device)
+    assert be.rebuild(None, good) == kept + ghosts.size
+    _, _, gid2, _ = be.solver.slab_read()
+    assert np.all(np.diff(gid2.astype(np.int64)) > 0)                  # merged set is sorted
+    be.step(1)
+    kept, down, up = be.pack()
+    bad = torch.from_numpy(msg[::-1].copy().view(np.int32).reshape(-1)).to(be.device)
+    be.rebuild(None, bad)
+    with pytest.raises(sphmi.SphError):
+        be.pack()
