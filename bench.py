@@ -208,7 +208,7 @@ def main():
                        "liquid_lattice": list(lattice), "cell_ids": "ref16" if mask == 0xffff else "wide",
                        "pcisph_iterations": cfg.maxIteration,
                        "parallelism": "1 GPU" if world == 1 else
-                       "%d z-slabs, 4-layer halo, 2 RCCL send/recv per rank per step" % world},
+                       "%d z-slabs, 4-layer halo, one RCCL send + recv per neighbour per step" % world},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms,
         }
@@ -216,7 +216,8 @@ def main():
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if decomposition is not None:
             out["halo"] = {"local_particles_rank0": solver.N, "bytes_sent_rank0_per_step": decomposition.bytes_sent // max(1, it),
-                           "exchange_host_ms_per_step_rank0": round(decomposition.exchange_seconds * 1e3 / max(1, it), 4)}
+                           "exchange_host_ms_per_step_rank0": round(decomposition.exchange_seconds * 1e3 / max(1, it), 4),
+                           "p2p_groups_per_step_rank0": round(decomposition.transfers / max(1, it), 3)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -2,8 +2,9 @@
 
 One process per GPU. The global box is cut into z-slabs of whole cell layers; each rank advances its own layers plus
 `GHOST_LAYERS` ghost layers per side with the ordinary fused step and, once per step, sends the authoritative particles
-that now lie within `GHOST_LAYERS` of a cut to the neighbouring rank (two point-to-point messages per rank per step, each
-riding one xGMI link; no collective on the data path). Ghost zones are replaced wholesale by what arrives.
+that now lie within `GHOST_LAYERS` of a cut to the neighbouring rank (one point-to-point message per neighbour per step — a
+count word, the payload and a little padding up to a length both ends derived from the previous step — each riding one
+xGMI link; no collective on the data path). Ghost zones are replaced wholesale by what arrives.
 
 Why 4 ghost layers: one PCISPH step propagates information over 6 neighbour hops (density 1, forces 2, and +1 per
 predict/correct half-iteration up to 6 for the last pressure force), each hop <= 31h/30, i.e. 6.2h < 4 cell layers (8h).
@@ -134,43 +135,91 @@ class SlabDecomposition:
             comm_device = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
         self.comm_device = torch.device(comm_device) if comm_device == "cpu" else getattr(backend, "device", torch.device("cuda"))
         self.bytes_sent = 0
+        self.transfers = 0          # batched point-to-point groups issued so far (1 per step in steady state)
+        self._bound_out, self._bound_in, self._frames = {}, {}, {}
 
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
 
+    # ---- message framing. A link direction carries ONE transfer per step: [count word | payload | padding] of an agreed
+    # length, so that the receiver can post its receive without first learning the size. Both ends of a link know the
+    # payload length of the previous step and derive the same bound for the next one (12.5 % + 1024 records of slack);
+    # the very first exchange, and a payload that outgrows its bound (the count word says so), use an explicit second
+    # transfer of exactly the missing words.
+    @staticmethod
+    def next_bound(words):
+        rec = words // SLAB_RECORD_WORDS
+        rec = rec + rec // 8 + 1024
+        return ((rec + 255) // 256) * 256 * SLAB_RECORD_WORDS
+
+    def _frame(self, key, words):
+        """A reusable int32 buffer of 1 + words entries on the communication device."""
+        t = self._frames.get(key)
+        if t is None or t.numel() < 1 + words:
+            t = self.torch.empty(1 + words, dtype=self.torch.int32, device=self.comm_device)
+            self._frames[key] = t
+        return t[:1 + words]
+
+    def _transfer(self, sends, recvs):
+        """One batched group of point-to-point operations: sends = [(tensor, peer)], recvs likewise."""
+        dist = self.dist
+        ops = [dist.P2POp(dist.isend, t, p) for t, p in sends] + [dist.P2POp(dist.irecv, t, p) for t, p in recvs]
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.comm_device.type == "cuda":
+            # RCCL completes on torch's communication stream; the host reads the count words and the rebuild kernels run
+            # on the solver's own stream
+            self.torch.cuda.synchronize(self.comm_device)
+
     def exchange(self):
-        torch, dist = self.torch, self.dist
+        torch = self.torch
         kept, msg_down, msg_up = self.backend.pack()
         if self.world == 1:
             return self.backend.rebuild(None, None)
-        P = dist.P2POp
-        # 1. sizes (one int each way), 2. payloads of exactly that size; each phase is one batched group of isend/irecv
-        n_send = {self.lower: msg_down.numel(), self.upper: msg_up.numel()}
-        size_out = {p: torch.tensor([n_send[p]], dtype=torch.int32, device=self.comm_device) for p in (self.lower, self.upper) if p is not None}
-        size_in = {p: torch.zeros(1, dtype=torch.int32, device=self.comm_device) for p in size_out}
-        ops = []
-        for p in size_out:
-            ops += [P(dist.isend, size_out[p], p), P(dist.irecv, size_in[p], p)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        n_recv = {p: int(size_in[p].item()) for p in size_in}
-        payload_out = {self.lower: msg_down, self.upper: msg_up}
-        recv = {p: torch.empty(n_recv[p], dtype=torch.int32, device=self.comm_device) for p in n_recv}
-        ops, keep = [], []
-        for p in n_recv:
-            if n_send[p] > 0:
-                t = self._to_comm(payload_out[p]).contiguous()
-                keep.append(t)
-                ops.append(P(dist.isend, t, p))
-                self.bytes_sent += 4 * n_send[p]
-            if n_recv[p] > 0:
-                ops.append(P(dist.irecv, recv[p], p))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        if self.comm_device.type == "cuda":
-            # RCCL completes on torch's communication stream; the rebuild kernels run on the solver's own stream
-            torch.cuda.synchronize(self.comm_device)
+        peers = [p for p in (self.lower, self.upper) if p is not None]
+        payload = {self.lower: msg_down, self.upper: msg_up}
+        n_out = {p: int(payload[p].numel()) for p in peers}
+        first = not self._bound_out
+        if first:  # no agreed bounds yet: the transfer carries only the count word
+            for p in peers:
+                self._bound_out[p] = 0
+                self._bound_in[p] = 0
+        out, inn = {}, {}
+        for p in peers:
+            b = self._bound_out[p]
+            f = self._frame(("out", p), b)
+            f[0:1] = torch.tensor([n_out[p]], dtype=torch.int32)
+            k = min(n_out[p], b)
+            if k:
+                f[1:1 + k] = self._to_comm(payload[p][:k])
+            out[p] = f
+            inn[p] = self._frame(("in", p), max(self._bound_in[p], 0))
+        self._transfer([(out[p], p) for p in peers], [(inn[p], p) for p in peers])
+        self.bytes_sent += sum(4 * out[p].numel() for p in peers)
+        n_in = {p: int(inn[p][0].item()) for p in peers}
+        # what did not fit the agreed bounds (always the case in the first exchange): exact sizes are now known to both ends
+        sends, recvs, recv = [], [], {}
+        for p in peers:
+            b_out, b_in = self._bound_out[p], self._bound_in[p]
+            if n_out[p] > b_out:
+                rest = self._to_comm(payload[p][b_out:]).contiguous()
+                sends.append((rest, p))
+                self.bytes_sent += 4 * rest.numel()
+            if n_in[p] > b_in:
+                full = torch.empty(n_in[p], dtype=torch.int32, device=self.comm_device)
+                if b_in:
+                    full[:b_in] = inn[p][1:1 + b_in]
+                recvs.append((full[b_in:], p))
+                recv[p] = full
+            else:
+                recv[p] = inn[p][1:1 + n_in[p]]
+        self._transfer(sends, recvs)
+        for p in peers:
+            self._bound_out[p] = self.next_bound(n_out[p])
+            self._bound_in[p] = self.next_bound(n_in[p])
+        self.transfers += 1 + (1 if (sends or recvs) else 0)
         return self.backend.rebuild(recv.get(self.lower), recv.get(self.upper))
 
     def step(self, iteration):

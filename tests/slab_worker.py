@@ -108,13 +108,16 @@ def main():
         backend = S.HipSlabBackend(cfg, pos, vel, idx, slab)
     else:
         backend = OracleSlabBackend(cfg, pos, vel, idx, slab)
+    if os.environ.get("SPHMI_TEST_BOUND_WORDS"):  # force the "payload outgrew its bound" path: tiny agreed bounds
+        words = int(os.environ["SPHMI_TEST_BOUND_WORDS"])
+        S.SlabDecomposition.next_bound = staticmethod(lambda n: words)
     dd = S.SlabDecomposition(backend, a.rank, a.world, dist, comm_device="cpu")  # gloo: messages staged through host
     counts = []
     for it in range(a.steps):
         counts.append(dd.step(it))
     gid, p, v = backend.owned_state()
     np.savez(os.path.join(a.out, "rank%d.npz" % a.rank), gid=gid, pos=p, vel=v, counts=np.array(counts),
-             cuts=np.array(cuts), sent=dd.bytes_sent)
+             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -27,11 +27,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(backend, world, out, steps=STEPS):
+def run_ranks(backend, world, out, steps=STEPS, env=None):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--backend", backend, "--steps", str(steps), "--out", str(out)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, **(env or {}))) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
@@ -82,6 +83,16 @@ def test_two_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
     results = run_ranks("oracle", 2, tmp_path)
     sc, pos_ref, vel_ref = single_domain_reference()
     check_union(results, sc, pos_ref, vel_ref)
+    # framing: the first exchange needs a second transfer (no agreed bound yet), every later step exactly one
+    assert all(int(r["transfers"]) == STEPS + 1 for r in results)
+
+
+def test_halo_payload_larger_than_the_agreed_bound_cpu(tmp_path):
+    """Bounds forced to 4 records: every step takes the remainder path (count word says more than fits), results unchanged."""
+    results = run_ranks("oracle", 2, tmp_path, steps=3, env={"SPHMI_TEST_BOUND_WORDS": str(4 * sphmi.SLAB_RECORD_WORDS)})
+    sc, pos_ref, vel_ref = single_domain_reference(steps=3)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert all(int(r["transfers"]) == 2 * 3 for r in results)
 
 
 def test_three_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
