@@ -40,6 +40,18 @@ int sphmi_generate_box(const sph_config* cfg, double xmax_in_h, double ymax_in_h
                        float spacing, float ox, float oy, float oz, float jitter, uint64_t seed, float* position4N,
                        float* velocity4N);
 
+/* The worm scene owHelper::generateConfiguration builds (owHelper.cpp:104-1429): an elastic worm shell
+ * (two radial layers, 199 cross-sections) with its triangulated membrane, springs to every elastic / boundary particle within
+ * r0*sqrt(2.7) (rest length 0.95 of the distance; lengthwise springs between "green" shell particles carry one of 96 muscle
+ * group colours), liquid inside the worm and on the floor of the box, and the boundary shell. Particle order: elastic,
+ * liquid, boundary (elasticOffset = 0). Bit-identical to the compiled reference generator for the shipped box
+ * (tests/golden/worm_input.npz). sphmi_worm_counts gives the sizes: position / velocity 4*(E+L+B) floats,
+ * elasticConnections 4*32*E floats, membraneData 3*M ints, particleMembranesList 7*E ints. */
+int sphmi_worm_counts(const sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, int* numOfElasticP,
+                      int* numOfLiquidP, int* numOfBoundaryP, int* numOfMembranes);
+int sphmi_generate_worm(const sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, float* position4N,
+                        float* velocity4N, float* elasticConnections, int32_t* membraneData, int32_t* particleMembranesList);
+
 /* owHelper::loadConfigurationToFile (owHelper.cpp:1640-1672), the `-l_to` trajectory dump: `<dir>/position_buffer.txt` gets
  * "numOfElasticP\nnumOfLiquidP\n" when firstIteration, then one `x\ty\tz\ttype` line per NON-boundary particle (appended
  * on later calls; the reference calls it every 10th step, owPhysicsFluidSimulator.cpp:121-129); on the first call also

@@ -4,6 +4,7 @@
 //
 //   sphmi_run --position P.txt --velocity V.txt [--steps N] [--staged] [--out positions.bin] [--quiet]
 //   sphmi_run --box 50 50 50 --lattice 100 100 100 [--wide] ...
+//   sphmi_run --worm [--muscles] ...      the generated worm scene of the reference's default start-up (owHelper.cpp:709)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +30,7 @@ struct Watch {  // owHelper::refreshTime / watch_report (owHelper.cpp:44-57,1806
 
 int main(int argc, char** argv) {
   const char *posFile = nullptr, *velFile = nullptr, *outFile = nullptr;
-  int steps = 10; bool staged = false, wide = false, quiet = false, muscles = false;
+  int steps = 10; bool staged = false, wide = false, quiet = false, muscles = false, worm = false;
   double box[3] = {0, 0, 0}; int lat[3] = {0, 0, 0};
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--position") && i + 1 < argc) posFile = argv[++i];
@@ -42,12 +43,14 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--wide")) wide = true;
     else if (!strcmp(argv[i], "--quiet")) quiet = true;
     else if (!strcmp(argv[i], "--muscles")) muscles = true;
+    else if (!strcmp(argv[i], "--worm")) worm = true;
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
     sph_config cfg;
     sphmi_default_config(&cfg);
-    std::vector<float> position_cpp, velocity_cpp;
+    std::vector<float> position_cpp, velocity_cpp, elasticConnectionsData_cpp;
+    std::vector<int> membraneData_cpp, particleMembranesList_cpp;
     int numOfLiquidP = 0, numOfElasticP = 0, numOfBoundaryP = 0;
     if (posFile && velFile) {  // owHelper::preLoadConfiguration + loadConfiguration
       int n = sphmi_count_particles(posFile);
@@ -57,6 +60,18 @@ int main(int argc, char** argv) {
       if (sphmi_load_configuration(posFile, velFile, n, position_cpp.data(), velocity_cpp.data(), &numOfLiquidP, &numOfElasticP, &numOfBoundaryP))
         throw std::runtime_error("could not load configuration");
       if (numOfElasticP) throw std::runtime_error("elastic particles need elasticconnections.txt, which the reference repository does not ship");
+    } else if (worm) {  // owHelper::generateConfiguration, shipped box (owPhysicsFluidSimulator.cpp:36-53)
+      int numOfMembranes = 0;
+      if (sphmi_worm_counts(&cfg, 30.0, 20.0, 250.0, &numOfElasticP, &numOfLiquidP, &numOfBoundaryP, &numOfMembranes)) throw std::runtime_error("worm scene: bad configuration");
+      cfg.particleCount = numOfElasticP + numOfLiquidP + numOfBoundaryP;
+      cfg.numOfElasticP = numOfElasticP; cfg.numOfMembranes = numOfMembranes; cfg.elasticOffset = 0;
+      position_cpp.resize(4 * (size_t)cfg.particleCount); velocity_cpp.resize(4 * (size_t)cfg.particleCount);
+      elasticConnectionsData_cpp.resize((size_t)4 * SPH_MAX_NEIGHBOR_COUNT * numOfElasticP);
+      membraneData_cpp.resize(3 * (size_t)numOfMembranes);
+      particleMembranesList_cpp.resize((size_t)SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE * numOfElasticP);
+      if (sphmi_generate_worm(&cfg, 30.0, 20.0, 250.0, position_cpp.data(), velocity_cpp.data(), elasticConnectionsData_cpp.data(),
+                              membraneData_cpp.data(), particleMembranesList_cpp.data()))
+        throw std::runtime_error("worm scene generation failed");
     } else if (box[0] > 0 && lat[0] > 0) {  // synthetic pure-liquid box, SURVEY 8(d)
       if (sphmi_config_set_box(&cfg, box[0], box[1], box[2], wide ? 0xffffffffu : 0xffffu)) throw std::runtime_error("bad box");
       if (sphmi_box_counts(&cfg, box[0], box[1], box[2], lat[0], lat[1], lat[2], &numOfLiquidP, &numOfBoundaryP)) throw std::runtime_error("bad lattice");
@@ -66,12 +81,15 @@ int main(int argc, char** argv) {
       if (sphmi_generate_box(&cfg, box[0], box[1], box[2], lat[0], lat[1], lat[2], sp, o, o, o, 0.f, 20261004ull, position_cpp.data(), velocity_cpp.data()))
         throw std::runtime_error("box generation failed");
     } else {
-      fprintf(stderr, "usage: sphmi_run (--position P --velocity V | --box X Y Z --lattice A B C) [--steps N] [--staged] [--wide] [--out F]\n");
+      fprintf(stderr, "usage: sphmi_run (--position P --velocity V | --box X Y Z --lattice A B C | --worm [--muscles]) [--steps N] [--staged] [--wide] [--out F]\n");
       return 2;
     }
     printf("particles: %d (liquid %d, elastic %d, boundary %d), grid %d x %d x %d\n", cfg.particleCount, numOfLiquidP,
            numOfElasticP, numOfBoundaryP, cfg.gridCellsX, cfg.gridCellsY, cfg.gridCellsZ);
-    owOpenCLSolver* ocl_solver = new owOpenCLSolver(cfg, position_cpp.data(), velocity_cpp.data());
+    owOpenCLSolver* ocl_solver = new owOpenCLSolver(cfg, position_cpp.data(), velocity_cpp.data(),
+                                                    elasticConnectionsData_cpp.empty() ? nullptr : elasticConnectionsData_cpp.data(),
+                                                    membraneData_cpp.empty() ? nullptr : membraneData_cpp.data(),
+                                                    particleMembranesList_cpp.empty() ? nullptr : particleMembranesList_cpp.data());
     std::vector<float> muscle_activation_signal_cpp(cfg.muscleCount, 0.f);
     Watch helper; helper.quiet = quiet;
     double total = 0;

@@ -68,6 +68,8 @@ def host_lib():
         L.sphmi_generate_box.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
         L.sphmi_muscle_signal.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.sphmi_worm_counts.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double] + [C.POINTER(C.c_int)] * 4
+        L.sphmi_generate_worm.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 5
         L.sphmi_save_configuration.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_int]
         _host = L
@@ -88,7 +90,8 @@ EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sp
                     "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
-                         "sphmi_generate_box", "sphmi_muscle_signal", "sphmi_save_configuration"]
+                         "sphmi_generate_box", "sphmi_muscle_signal", "sphmi_save_configuration", "sphmi_worm_counts",
+                         "sphmi_generate_worm"]
 
 
 def device_lib():
@@ -188,6 +191,29 @@ def generate_box(cfg, lx, ly, lz, spacing=None, origin=None, jitter=0.0, seed=20
         raise SphError("sphmi_generate_box failed: %d" % rc)
     cfg.particleCount = n
     return pos, vel, dict(numOfLiquidP=nl.value, numOfElasticP=0, numOfBoundaryP=nb.value)
+
+
+def generate_worm(cfg):
+    """The reference's generated worm scene (owHelper::generateConfiguration) for cfg's box. Sets
+    cfg.particleCount / numOfElasticP / numOfMembranes / elasticOffset and returns a scene dict."""
+    bx = cfg._box_in_h
+    ne, nl, nb, nm = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = host_lib().sphmi_worm_counts(C.byref(cfg), bx[0], bx[1], bx[2], C.byref(ne), C.byref(nl), C.byref(nb), C.byref(nm))
+    if rc:
+        raise SphError("sphmi_worm_counts failed: %d" % rc)
+    n = ne.value + nl.value + nb.value
+    pos = np.empty((n, 4), np.float32)
+    vel = np.empty((n, 4), np.float32)
+    elastic = np.empty((ne.value * 32, 4), np.float32)
+    membranes = np.empty((nm.value, 3), np.int32)
+    pml = np.empty((ne.value, 7), np.int32)
+    rc = host_lib().sphmi_generate_worm(C.byref(cfg), bx[0], bx[1], bx[2], pos.ctypes.data, vel.ctypes.data, elastic.ctypes.data,
+                                        membranes.ctypes.data, pml.ctypes.data)
+    if rc:
+        raise SphError("sphmi_generate_worm failed: %d" % rc)
+    cfg.particleCount, cfg.numOfElasticP, cfg.numOfMembranes, cfg.elasticOffset = n, ne.value, nm.value, 0
+    return dict(cfg=cfg, position=pos, velocity=vel, elastic=elastic, membranes=membranes, particle_membranes=pml,
+                numOfLiquidP=nl.value, numOfElasticP=ne.value, numOfBoundaryP=nb.value)
 
 
 def save_configuration(directory, position, num_elastic, num_liquid, connections=None, membranes=None, first=True):

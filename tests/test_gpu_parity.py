@@ -357,3 +357,17 @@ def test_cpp_driver_matches_reference_fixture(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         pos = np.fromfile(out, np.float32).reshape(-1, 4)
         assert scenes.bits_equal(pos[z["sample_ids"]], z["position_sample_9"])
+
+
+def test_cpp_driver_generated_worm_scene_matches_reference_fixture(tmp_path):
+    """sphmi_run --worm: scene from the restated generator, muscle signals from sphmi_muscle_signal, fused
+    steps through the C++ facade; positions after 10 steps against the compiled reference (same fixture as the Python test)."""
+    import subprocess
+    z = np.load(os.path.join(scenes.GOLDEN, "worm.npz"))
+    out = tmp_path / "pos.bin"
+    r = subprocess.run([os.path.join(scenes.PKG, "sphmi_run"), "--worm", "--muscles", "--steps", "10", "--quiet", "--out", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pos = np.fromfile(out, np.float32).reshape(-1, 4)
+    assert pos.shape[0] == 232887
+    assert scenes.bits_equal(pos[z["sample_ids"]], z["position_sample_9"])

@@ -193,3 +193,38 @@ def test_frame_feed_inversion_and_writers(tmp_path):
     rgb = frames.density_colour(np.float32([990, 1005, 1015, 1025, 1035, 1100]), 1000.0)
     assert np.allclose(rgb[0], (0, 0, 1)) and np.allclose(rgb[1], (0, 0.5, 1)) and np.allclose(rgb[2], (0, 1, 0.5))
     assert np.allclose(rgb[3], (0.5, 1, 0)) and np.allclose(rgb[4], (1, 0.5, 0)) and np.allclose(rgb[5], (1, 0, 0))
+
+
+def test_worm_generator_matches_reference_fixture():
+    """SURVEY 8 f1: sphmi_generate_worm restates owHelper::generateConfiguration (owHelper.cpp:104-1429). Pinned against the
+    output of the compiled reference generator (tests/golden/worm_input.npz, made by tests/golden/make_golden.py): particle
+    counts, every position / velocity bit, all 137,804 springs with their rest lengths and muscle colours, the 11,386
+    membrane triangles and the per-particle triangle lists."""
+    z = np.load(scenes.worm_scene_path())
+    cfg = sphmi.default_config()
+    sc = sphmi.generate_worm(cfg)
+    assert (sc["numOfElasticP"], sc["numOfLiquidP"], sc["numOfBoundaryP"]) == (10143, 120336, 102408)
+    assert cfg.particleCount == 232887 and cfg.numOfElasticP == 10143 and cfg.numOfMembranes == 11386
+    for mine, ref in (("position", "position"), ("velocity", "velocity"), ("elastic", "elastic")):
+        assert scenes.bits_equal(sc[mine], z[ref]), mine
+    assert np.array_equal(sc["membranes"], z["membranes"])
+    assert np.array_equal(sc["particle_membranes"], z["particle_membranes"])
+    el = sc["elastic"]
+    live = el[:, 0] >= 0
+    assert int(live.sum()) == 137804
+    muscles = np.unique(el[live, 2].astype(np.int32))
+    assert muscles[0] == 0 and set(range(1, 97)) <= set(muscles.tolist())  # 96 muscle groups, quadrants of 24
+
+
+def test_worm_generator_other_box():
+    """A different box moves the worm axis and changes the liquid / boundary counts; structure stays consistent."""
+    cfg = sphmi.default_config()
+    sphmi.set_box(cfg, 30.0, 20.0, 260.0, 0xffff)
+    sc = sphmi.generate_worm(cfg)
+    n = cfg.particleCount
+    assert n == sc["numOfElasticP"] + sc["numOfLiquidP"] + sc["numOfBoundaryP"] and sc["numOfElasticP"] == 10143
+    t = sc["position"][:, 3].astype(np.int32)
+    assert np.all(t[:10143] == 2) and np.all(t[10143:10143 + sc["numOfLiquidP"]] == 1) and np.all(t[-sc["numOfBoundaryP"]:] == 3)
+    assert sc["membranes"].min() >= 0 and sc["membranes"].max() < 10143
+    ids = sc["elastic"][:, 0]
+    assert np.all((ids == -1) | ((ids >= 0) & (ids < n)))
