@@ -105,15 +105,16 @@ def test_trajectory_dump_format(tmp_path):
     assert int(mem[0]) == sc["membranes"].shape[0] and [int(v) for v in mem[1].split("\t")] == list(sc["membranes"][0]) + [0]
 
 
-def test_muscle_signal_closed_form():
-    """main_sim.py:4-53 in closed form (parity unpinned: the Python-2 script cannot run here; formula by inspection)."""
-    s0 = sphmi.muscle_signal(0)
-    assert s0.shape == (100,) and np.all(s0[96:] == 0)
-    k = np.repeat(np.arange(12), 2)
-    w1 = (np.sin(k * 3 * np.pi / 11) + 1) / 2
-    w2 = (np.sin(k * 3 * np.pi / 11 + np.pi) + 1) / 2
-    np.testing.assert_allclose(s0[:96], np.concatenate([w1, w2, w2, w1]), atol=1e-7)
-    s5 = sphmi.muscle_signal(50000)
+def test_muscle_signal_matches_reference_generator():
+    """sphmi_muscle_signal against values produced by the reference's own main_sim.py (fixture
+    tests/golden/muscle_signal.npz, generated by tests/golden/make_muscle_golden.py), narrowed to float as
+    PyramidalSimulation::unpackPythonList does: bit-identical at every sampled step."""
+    z = np.load(os.path.join(scenes.GOLDEN, "muscle_signal.npz"))
+    for t, want in zip(z["steps"], z["signal_f32"]):
+        s = sphmi.muscle_signal(int(t))
+        assert s.shape == (100,) and np.all(s[96:] == 0)      # MUSCLE_COUNT = 100, entries 96..99 stay 0
+        assert scenes.bits_equal(s[:96], want), "step %d" % t
+    s0, s5 = sphmi.muscle_signal(0), sphmi.muscle_signal(50000)
     assert np.abs(s5[:96] - s0[:96]).max() > 0.1  # the wave travels
 
 
