@@ -183,6 +183,28 @@ def main():
                 elif workload_name in tr.get("other_workloads", {}):
                     roofline["traffic"] = tr["other_workloads"][workload_name]["hbm_bytes_per_launch"]
 
+    # SURVEY 8(d) extras, single GPU only and outside `value`: per-step p50 from one event pair per step, and the step
+    # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step).
+    p50_ms, readback_ms = None, None
+    if world == 1:
+        k3 = max(5, min(args.steps, 50))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k3 + 1)]
+        with torch.cuda.stream(stream):
+            evs[0].record(stream)
+            for i in range(k3):
+                stepper.step(it); it += 1
+                evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
+        p50_ms = per_step[len(per_step) // 2]
+        host_pos = np.empty((N, 4), np.float32)
+        solver.synchronize()
+        r0 = time.perf_counter()
+        for _ in range(k3):
+            stepper.step(it); it += 1
+            solver.read_position_buffer(host_pos)
+        readback_ms = (time.perf_counter() - r0) * 1e3 / k3
+
     # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
     cpu = None
     if rank == 0 and args.cpu_steps > 0 and world == 1:
@@ -197,6 +219,15 @@ def main():
                "sample": "%d steps of the same %d-particle scene after 1 warm-up step (oracle/sph_oracle.c, OpenMP)"
                          % (args.cpu_steps, N), "ms_per_step": round(cw * 1e3 / args.cpu_steps, 2)}
         ora.close()
+        one = scenes.oracle_for(sc, threads=1)  # the 1-thread figure SURVEY 8(d) asks for beside the all-cores one
+        one.step()
+        c0 = time.perf_counter()
+        n1 = max(1, min(2, args.cpu_steps))
+        for _ in range(n1):
+            one.step()
+        c1 = time.perf_counter() - c0
+        one.close()
+        cpu["single_thread_value"] = round(N * n1 / c1, 1)
 
     if rank == 0:
         out = {
@@ -210,6 +241,8 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                        "%d z-slabs, 4-layer halo, one RCCL send + recv per neighbour per step" % world},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "ms_per_step_p50": None if p50_ms is None else round(p50_ms, 4),
+            "ms_per_step_with_position_readback": None if readback_ms is None else round(readback_ms, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms,
         }
         if cpu:
