@@ -228,6 +228,53 @@ def test_wide_mode_large_grid_properties():
     assert scenes.bits_equal(hip.read_position_buffer(), ora.buffer("position").reshape(-1, 4)[:N])
 
 
+def test_config4_sixteen_million_box_properties():
+    """BASELINE config #4 at full size (16,507,704 particles, wide cell ids, 1.9 M cells): too large for the oracle in a test,
+    so size-independent properties of one step: sorted keys with ascending-id ties, permutation + inverse, cell table =
+    lower_bound, every neighbour distance recomputable bit for bit from the sorted positions and inside the search radius,
+    no self / duplicate neighbours, and the density recomputed from the stored distances in slot order (f64, like
+    pcisph_computeDensity) equal bit for bit."""
+    sc = scenes.liquid_box((78.0, 50.0, 470.0), (160, 100, 1000), mask=0xffffffff)
+    cfg = sc["cfg"]
+    N = cfg.particleCount
+    assert N == 16507704
+    hip = scenes.hip_for(sc)
+    hip._runClearBuffers(); hip._runHashParticles(); hip._runSort(); hip._runSortPostPass(); hip._runIndexx()
+    hip._runIndexPostPass(); hip._runFindNeighbors(); hip._run_pcisph_computeDensity()
+    keys, vals = _check_search_structures(hip, cfg, N)
+    assert keys.max() > 65535
+    nm = hip.buffer("neighborMap").reshape(N, 32, 2)
+    ids = hip.buffer("neighborIds").reshape(N, 32)
+    dist = nm[:, :, 1]
+    assert np.array_equal(nm[:, :, 0].astype(np.int32), ids)            # float-coded ids of the reference layout
+    valid = ids >= 0
+    assert np.array_equal(valid, dist != -1.0)
+    assert np.all(np.cumsum(~valid, axis=1)[valid] == 0), "empty slots must come last"
+    assert valid.sum() > 30 * (N - 600000), "the liquid bulk must have (nearly) full lists"
+    spos = hip.buffer("sortedPosition").reshape(-1, 4)[:N]
+    simScale, h = np.float32(cfg.simulationScale), np.float32(cfg.h)
+    rmax2 = (np.float32(31) * h / np.float32(30)) ** 2
+    rho = np.zeros(N, np.float64)
+    hs2 = (h * simScale) * (h * simScale)
+    own = np.arange(N, dtype=np.int64)
+    for k in range(32):                                                  # slot by slot: 16.5 M-element vector operations
+        v = valid[:, k]
+        j = ids[:, k].astype(np.int64)
+        assert not np.any(j[v] == own[v]), "a particle lists itself"
+        if k:
+            assert not np.any(v & (ids[:, k] == ids[:, k - 1])), "duplicate neighbour"
+        e = spos[own[v], :3] - spos[j[v], :3]
+        d2 = (e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2]
+        assert np.all(d2 <= rmax2)
+        assert scenes.bits_equal(np.sqrt(d2) * simScale, dist[v, k]), "slot %d: stored distance != sqrt(d2)*simulationScale" % k
+        r2 = dist[:, k] * dist[:, k]
+        a = hs2 - r2
+        rho += np.where(v, (a * a * a).astype(np.float64), 0.0)
+    hs6 = np.float64((hs2 * hs2) * hs2)
+    rho = np.maximum(rho, hs6) * (np.float64(np.float32(cfg.mass)) * np.float64(cfg.Wpoly6Coefficient))
+    assert scenes.bits_equal(rho.astype(np.float32), hip.read_density_buffer())
+
+
 def test_ragged_sizes_and_single_particle_cells():
     """N not a multiple of 64/256/4096, and a sparse scene where most cells hold one particle."""
     for lattice, spacing in (((7, 5, 3), 0.93), ((3, 3, 3), 2.9), ((1, 1, 1), 0.93)):
