@@ -304,6 +304,36 @@ def test_overcrowded_cells_take_the_fallback_paths():
     assert (nm[:, 31] >= 0).sum() > 1000  # many full lists
 
 
+def test_evolved_dam_break_state_parity():
+    """Parity on DISORDERED states: a liquid column (110 k particles + 35 k boundary) collapses for 1,500 steps on the GPU — free fall,
+    impact on the floor, a front running along it; at three checkpoints the GPU state is handed to the oracle and one more
+    step of both is compared word for word (neighbour ids and distances, densities, pressures, accelerations, positions,
+    velocities). Lattice scenes never produce the cell occupancies and list lengths this does."""
+    sc = scenes.liquid_box((60.0, 30.0, 30.0), (40, 55, 50), origin_in_r0=(3.0, 3.0, 3.0))
+    cfg = sc["cfg"]
+    N, L = cfg.particleCount, 40 * 55 * 50
+    hip = scenes.hip_for(sc)
+    y0, x0 = sc["position"][:L, 1].mean(), sc["position"][:L, 0].max()
+    done = 0
+    for checkpoint in (500, 1000, 1500):
+        for it in range(done, checkpoint):
+            hip.step(it)
+        done = checkpoint
+        pos, vel = hip.read_position_buffer(), hip.read_velocity_buffer()
+        assert np.all(np.isfinite(pos)) and np.all(np.isfinite(vel))
+        state = dict(sc, position=pos.copy(), velocity=vel.copy())
+        ora = scenes.oracle_for(state, threads=16)
+        hip.reset_stage_times()
+        hip.step(checkpoint)
+        ora.step()
+        done += 1
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "dam break, step %d" % checkpoint, FUSED_SKIP)
+        ora.close()
+    pos = hip.read_position_buffer()
+    assert y0 - pos[:L, 1].mean() > 20.0, "the column must have collapsed (oracle alone: 47.6 -> 20.9)"
+    assert pos[:L, 0].max() - x0 > 60.0, "the front must have run along the floor (oracle alone: 65 -> 140)"
+
+
 def test_coincident_particles_neighbour_search():
     """Particles at identical positions (d = 0): found as each other's first-bin neighbours with distance 0; compared up to
     the density pass (beyond it the reference divides by r = 0, sphFluid.cl:1172-1178)."""
