@@ -109,6 +109,15 @@ def test_two_rank_halo_exchange_matches_single_domain_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_three_rank_halo_exchange_matches_single_domain_gpu(tmp_path):
+    """Three HIP ranks on the one card: the middle rank has a neighbour on both sides (both message merges, both frames)."""
+    results = run_ranks("hip", 3, tmp_path, steps=6)
+    sc, pos_ref, vel_ref = single_domain_reference(steps=6)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert all(int(r["transfers"]) == 6 + 1 for r in results)
+
+
+@pytest.mark.gpu
 def test_single_rank_slab_backend_equals_plain_solver():
     """world = 1: pack + rebuild every step (sort by global id) must not change anything."""
     sc = scenes.liquid_box((8.0, 8.0, 20.0), (12, 10, 30), mask=0xffffffff, jitter_in_r0=0.05)
