@@ -156,6 +156,10 @@ int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t* globalIds
  * `capRecords`), every list in ascending global-id order (order-preserving compaction of the sorted local set).
  * Blocking (the counts come back to the host). */
 int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t capRecords, int32_t counts[3]);
+/* The same, for callers that ship a message as ONE transfer `[count word | payload | padding]` (sphmi/slab.py): frame buffers
+ * have room for 1 + 9*capRecords words; word 0 receives the number of payload words (9 x records), written on the device, and
+ * the payload starts at word 1 — the frame can be handed to RCCL as it is. */
+int sph_slab_pack_framed(sph_solver* s, void* frameDown, void* frameUp, int32_t capRecords, int32_t counts[3]);
 /* New local set = kept + nDown records received from below + nUp from above, sorted by global id (three-way merge: the
  * received messages must be in ascending global-id order, as sph_slab_pack writes them; a message that is not makes the
  * next sph_slab_pack fail with SPH_ERR_INVALID). */

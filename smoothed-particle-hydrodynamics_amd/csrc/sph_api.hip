@@ -631,11 +631,9 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
   return SPH_OK;
 }
 
-extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t capRecords, int32_t counts[3]) {
-  ENTER(s);
-  if (!s->hasSlab || !counts || capRecords < 0 || ((s->slab.hasLower && !msgDown) || (s->slab.hasUpper && !msgUp))) {
-    sph_set_error("sph_slab_pack: slab not initialised or null message buffer"); return SPH_ERR_INVALID; }
-  int rc = sphk_slab_pack(s, (uint32_t*)msgDown, (uint32_t*)msgUp, capRecords);
+static int slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int32_t capRecords, int32_t counts[3], uint32_t* headDown,
+                     uint32_t* headUp) {
+  int rc = sphk_slab_pack(s, msgDown, msgUp, capRecords, headDown, headUp);
   if (rc != SPH_OK) return rc;
   uint32_t h[4];
   SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
@@ -649,6 +647,22 @@ extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t 
   s->slabKept = (int)h[0];
   if ((int)h[1] > capRecords || (int)h[2] > capRecords) { sph_set_error("halo message overflow: %u / %u records, room for %d", h[1], h[2], capRecords); return SPH_ERR_SIZE; }
   return SPH_OK;
+}
+
+extern "C" int sph_slab_pack(sph_solver* s, void* msgDown, void* msgUp, int32_t capRecords, int32_t counts[3]) {
+  ENTER(s);
+  if (!s->hasSlab || !counts || capRecords < 0 || ((s->slab.hasLower && !msgDown) || (s->slab.hasUpper && !msgUp))) {
+    sph_set_error("sph_slab_pack: slab not initialised or null message buffer"); return SPH_ERR_INVALID; }
+  return slab_pack(s, (uint32_t*)msgDown, (uint32_t*)msgUp, capRecords, counts, nullptr, nullptr);
+}
+
+extern "C" int sph_slab_pack_framed(sph_solver* s, void* frameDown, void* frameUp, int32_t capRecords, int32_t counts[3]) {
+  ENTER(s);
+  if (!s->hasSlab || !counts || capRecords < 0 || ((s->slab.hasLower && !frameDown) || (s->slab.hasUpper && !frameUp))) {
+    sph_set_error("sph_slab_pack_framed: slab not initialised or null frame buffer"); return SPH_ERR_INVALID; }
+  uint32_t* fd = (uint32_t*)frameDown;
+  uint32_t* fu = (uint32_t*)frameUp;
+  return slab_pack(s, fd ? fd + 1 : nullptr, fu ? fu + 1 : nullptr, capRecords, counts, fd, fu);
 }
 
 extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp) {

@@ -144,7 +144,8 @@ int sphk_correct_pressure(sph_solver* s);
 int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth = -1);  // 0 none, 1 + predictPositions, 2 + integrate
 int sphk_integrate(sph_solver* s);
 // sph_slab.hip
-int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords);
+int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords, uint32_t* headDown = nullptr,
+                   uint32_t* headUp = nullptr);  // head*: where to store the payload word count of each message (framed mode)
 int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept);  // 3-way merge
 int sphk_slab_sort_rebuild(sph_solver* s, int total);  // staging area in any order -> local set sorted by global id
 // sph_elastic.hip

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab
 
 // blockOffsets[b][c] = sum of blockCounts[b'][c] over b' < b; counts[c] = grand totals. One workgroup, 256 blocks per trip.
 __global__ __launch_bounds__(SPH_BLOCK) void k_slab_scan(const uint32_t* __restrict__ blockCounts, uint32_t* __restrict__ blockOffsets,
-                                                         int nb, uint32_t* __restrict__ counts) {
+                                                         int nb, uint32_t* __restrict__ counts, uint32_t* __restrict__ headDown,
+                                                         uint32_t* __restrict__ headUp) {
   __shared__ uint32_t buf[SPH_BLOCK][3];
   __shared__ uint32_t carry[3];
   const int tid = threadIdx.x;
@@ -107,14 +108,17 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_scan(const uint32_t* __restr
     __syncthreads();
   }
   if (tid < 3) counts[tid] = carry[tid];
+  // framed messages ([payload words | payload | padding], sph_slab_pack_framed): the count word is written here, on the device
+  if (tid == 1 && headDown) *headDown = carry[1] * REC;
+  if (tid == 2 && headUp) *headUp = carry[2] * REC;
 }
 
-int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords) {
+int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords, uint32_t* headDown, uint32_t* headUp) {
   const int nb = sph_blocks(s->d.N, PACK_SPAN);
   uint32_t* blockCounts = s->blockHist;  // the radix-sort workspace is idle between two steps: >= capacity/16 words
   uint32_t* blockOffsets = s->blockHist + (size_t)nb * 4;
   hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords);
-  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, s->slabCounts);
+  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, s->slabCounts, headDown, headUp);
   hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords);
   SPH_HIP(hipGetLastError());
   return SPH_OK;

@@ -85,9 +85,10 @@ class HipSlabBackend:
         self.solver.slab_init(slab, global_ids)
         self.cap_records = cfg.capacity // 2
         dev = torch.device("cuda", cfg.device)
-        self.msg_down = torch.empty(self.cap_records * SLAB_RECORD_WORDS, dtype=torch.int32, device=dev)
-        self.msg_up = torch.empty_like(self.msg_down)
-        self.device = dev
+        # message frames: [payload word count | records ...]; libsphmi writes both parts on the device (sph_slab_pack_framed)
+        self.frame_down = torch.empty(1 + self.cap_records * SLAB_RECORD_WORDS, dtype=torch.int32, device=dev)
+        self.frame_up = torch.empty_like(self.frame_down)
+        self.device = self.frame_device = dev
 
     @property
     def count(self):
@@ -96,10 +97,15 @@ class HipSlabBackend:
     def step(self, iteration):
         self.solver.step(iteration)
 
+    def pack_framed(self):
+        """(kept, frame_down, payload words, frame_up, payload words): frames ready to be sent from word 0."""
+        kept, nd, nu = self.solver.slab_pack_framed(C.c_void_p(self.frame_down.data_ptr()), C.c_void_p(self.frame_up.data_ptr()),
+                                                    self.cap_records)
+        return kept, self.frame_down, nd * SLAB_RECORD_WORDS, self.frame_up, nu * SLAB_RECORD_WORDS
+
     def pack(self):
-        kept, nd, nu = self.solver.slab_pack(C.c_void_p(self.msg_down.data_ptr()), C.c_void_p(self.msg_up.data_ptr()),
-                                             self.cap_records)
-        return kept, self.msg_down[:nd * SLAB_RECORD_WORDS], self.msg_up[:nu * SLAB_RECORD_WORDS]
+        kept, fd, nd, fu, nu = self.pack_framed()
+        return kept, fd[1:1 + nd], fu[1:1 + nu]
 
     def rebuild(self, recv_down, recv_up):
         keep = []  # the received tensors must outlive the asynchronous rebuild kernels: released at the next rebuild
@@ -175,12 +181,22 @@ class SlabDecomposition:
 
     def exchange(self):
         torch = self.torch
-        kept, msg_down, msg_up = self.backend.pack()
+        # Zero-copy framing when the backend keeps [count | payload] frames on the communication device (HipSlabBackend under
+        # RCCL): the frame is sent as it is. Otherwise (CPU-staged tests, other backends) frames are assembled here.
+        zero_copy = hasattr(self.backend, "pack_framed") and getattr(self.backend, "frame_device", None) == self.comm_device
+        if zero_copy:
+            kept, frame_down, nd, frame_up, nu = self.backend.pack_framed()
+            frames = {self.lower: frame_down, self.upper: frame_up}
+            n_words = {self.lower: nd, self.upper: nu}
+            payload = None
+        else:
+            kept, msg_down, msg_up = self.backend.pack()
+            payload = {self.lower: msg_down, self.upper: msg_up}
+            n_words = {p: int(t.numel()) for p, t in payload.items()}
         if self.world == 1:
             return self.backend.rebuild(None, None)
         peers = [p for p in (self.lower, self.upper) if p is not None]
-        payload = {self.lower: msg_down, self.upper: msg_up}
-        n_out = {p: int(payload[p].numel()) for p in peers}
+        n_out = {p: n_words[p] for p in peers}
         first = not self._bound_out
         if first:  # no agreed bounds yet: the transfer carries only the count word
             for p in peers:
@@ -189,22 +205,27 @@ class SlabDecomposition:
         out, inn = {}, {}
         for p in peers:
             b = self._bound_out[p]
-            f = self._frame(("out", p), b)
-            f[0:1] = torch.tensor([n_out[p]], dtype=torch.int32)
-            k = min(n_out[p], b)
-            if k:
-                f[1:1 + k] = self._to_comm(payload[p][:k])
-            out[p] = f
+            if zero_copy and 1 + b <= frames[p].numel():
+                out[p] = frames[p][:1 + b]
+            else:  # assemble the frame here (also when the agreed length outgrows the backend's own buffer)
+                src = frames[p][1:1 + n_out[p]] if zero_copy else payload[p]
+                f = self._frame(("out", p), b)
+                f[0:1] = torch.tensor([n_out[p]], dtype=torch.int32)
+                k = min(n_out[p], b)
+                if k:
+                    f[1:1 + k] = self._to_comm(src[:k])
+                out[p] = f
             inn[p] = self._frame(("in", p), max(self._bound_in[p], 0))
         self._transfer([(out[p], p) for p in peers], [(inn[p], p) for p in peers])
         self.bytes_sent += sum(4 * out[p].numel() for p in peers)
-        n_in = {p: int(inn[p][0].item()) for p in peers}
+        heads = torch.stack([inn[p][0] for p in peers]).cpu().tolist()  # one device->host copy for all count words
+        n_in = dict(zip(peers, (int(v) for v in heads)))
         # what did not fit the agreed bounds (always the case in the first exchange): exact sizes are now known to both ends
         sends, recvs, recv = [], [], {}
         for p in peers:
             b_out, b_in = self._bound_out[p], self._bound_in[p]
             if n_out[p] > b_out:
-                rest = self._to_comm(payload[p][b_out:]).contiguous()
+                rest = frames[p][1 + b_out:1 + n_out[p]] if zero_copy else self._to_comm(payload[p][b_out:]).contiguous()
                 sends.append((rest, p))
                 self.bytes_sent += 4 * rest.numel()
             if n_in[p] > b_in:

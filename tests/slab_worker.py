@@ -35,6 +35,8 @@ class OracleSlabBackend:
         self.cfg, self.slab = cfg, slab
         self.pos, self.vel, self.gid = position.copy(), velocity.copy(), global_ids.copy()
         self.owned = self._owned(self.pos)
+        if os.environ.get("SPHMI_TEST_FRAMED"):
+            self.frame_device = torch.device("cpu")
 
     def _owned(self, pos):
         lay = S.particle_layers(pos, self.cfg)
@@ -65,6 +67,17 @@ class OracleSlabBackend:
         up = a & (lay >= self.slab.layerHi - self.slab.ghostLayers) & bool(self.slab.hasUpper)
         self._kept = (self.pos[a], self.vel[a], self.gid[a])
         return int(a.sum()), self._records(down), self._records(up)
+
+    def pack_framed(self):
+        """[payload word count | payload] frames on the CPU, like HipSlabBackend's in HBM (exercises the zero-copy path)."""
+        kept, down, up = self.pack()
+        frames = []
+        for t in (down, up):
+            f = self.torch.zeros(1 + 2 * t.numel() + 8192 * REC, dtype=self.torch.int32)  # room for the agreed padding
+            f[0] = t.numel()
+            f[1:1 + t.numel()] = t
+            frames.append(f)
+        return kept, frames[0], int(down.numel()), frames[1], int(up.numel())
 
     def rebuild(self, recv_down, recv_up):
         parts = [self._kept]

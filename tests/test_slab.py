@@ -87,6 +87,15 @@ def test_two_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
     assert all(int(r["transfers"]) == STEPS + 1 for r in results)
 
 
+def test_backend_owned_frames_are_sent_in_place_cpu(tmp_path):
+    """The zero-copy path of the exchange (frames owned by the backend and sent as they are — what HipSlabBackend does under
+    RCCL), exercised here with CPU frames; also with bounds smaller than the payload (remainder taken from inside the frame)."""
+    sc, pos_ref, vel_ref = single_domain_reference(steps=3)
+    for extra in ({}, {"SPHMI_TEST_BOUND_WORDS": str(4 * sphmi.SLAB_RECORD_WORDS)}):
+        results = run_ranks("oracle", 3, tmp_path, steps=3, env=dict({"SPHMI_TEST_FRAMED": "1"}, **extra))
+        check_union(results, sc, pos_ref, vel_ref)
+
+
 def test_halo_payload_larger_than_the_agreed_bound_cpu(tmp_path):
     """Bounds forced to 4 records: every step takes the remainder path (count word says more than fits), results unchanged."""
     results = run_ranks("oracle", 2, tmp_path, steps=3, env={"SPHMI_TEST_BOUND_WORDS": str(4 * sphmi.SLAB_RECORD_WORDS)})
