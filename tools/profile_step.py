@@ -7,7 +7,8 @@ import scenes  # noqa: E402
 
 WORK = {"1M": ((50.0, 50.0, 50.0), (100, 100, 100), 0xffff), "4M": ((80.0, 80.0, 80.0), (160, 160, 160), 0xffffffff),
         "8M": ((100.0, 100.0, 100.0), (200, 200, 200), 0xffffffff),
-        "16M": ((78.0, 50.0, 470.0), (160, 100, 1000), 0xffffffff)}
+        "16M": ((78.0, 50.0, 470.0), (160, 100, 1000), 0xffffffff),
+        "64M": ((240.0, 200.0, 310.0), (250, 400, 640), 0xffffffff)}
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "1M"
