@@ -91,7 +91,10 @@ def main():
         backend_name = os.environ.get("SPHMI_DIST_BACKEND", "nccl")
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend_name, rank=rank, world_size=world)
+        if backend_name == "nccl":  # bind the communicator to this rank's GPU explicitly (one process per GPU)
+            dist.init_process_group(backend_name, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend_name, rank=rank, world_size=world)
         dist.barrier()  # creates the communicator with every rank present before the first point-to-point exchange
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libsphmi has no CPU path")

@@ -127,6 +127,20 @@ def test_three_rank_halo_exchange_matches_single_domain_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_slabs_exchange_frames_over_rccl_in_one_process(tmp_path):
+    """The RCCL path on the 1-GPU test box (tests/rccl_pair_worker.py): two slabs, real `batch_isend_irecv` on a world-1 NCCL
+    group (self sends), HipSlabBackend frames sent in place. Union of the owned particles == single-domain oracle, bit for bit."""
+    steps = 6
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_pair_worker.py"), "--steps", str(steps), "--port", str(free_port()),
+                        "--out", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    results = [np.load(os.path.join(tmp_path, "rank%d.npz" % k)) for k in range(2)]
+    sc, pos_ref, vel_ref = single_domain_reference(steps=steps)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert all(int(x["transfers"]) == steps + 1 for x in results)   # one framed transfer per step after the first exchange
+
+
+@pytest.mark.gpu
 def test_single_rank_slab_backend_equals_plain_solver():
     """world = 1: pack + rebuild every step (sort by global id) must not change anything."""
     sc = scenes.liquid_box((8.0, 8.0, 20.0), (12, 10, 30), mask=0xffffffff, jitter_in_r0=0.05)
