@@ -1,5 +1,6 @@
+"""Debug helper (test infrastructure: uses the oracle as the checker): first particles whose neighbour lists differ."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, scenes
 sc = scenes.liquid_box((8.0, 8.0, 8.0), (18, 18, 18), spacing_in_r0=0.45, origin_in_r0=(4.0, 4.0, 4.0))
 N = sc["cfg"].particleCount
