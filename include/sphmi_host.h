@@ -61,6 +61,15 @@ int sphmi_generate_worm(const sph_config* cfg, double xmax_in_h, double ymax_in_
 int sphmi_save_configuration(const char* dir, const float* position4N, int count, int numOfElasticP, int numOfLiquidP,
                              const float* connections, const int32_t* membranes, int numOfMembranes, int firstIteration);
 
+/* owHelper::loadConfigurationFromFile (owHelper.cpp:1674-1741): the `-l_from` playback input, i.e. the files
+ * sphmi_save_configuration writes. _info gives the particle counts, the number of complete frames in position_buffer.txt and
+ * the membrane count; _frame fills 4*(numOfElasticP+numOfLiquidP) floats; _connections 4*32*numOfElasticP floats;
+ * _membranes 4*numOfMembranes ints (rows `i j k unused`, as the reference reads them). */
+int sphmi_trajectory_info(const char* dir, int* numOfElasticP, int* numOfLiquidP, int* frames, int* numOfMembranes);
+int sphmi_trajectory_frame(const char* dir, int frame, float* position);
+int sphmi_trajectory_connections(const char* dir, int numOfElasticP, float* connections);
+int sphmi_trajectory_membranes(const char* dir, int numOfMembranes, int32_t* membranes);
+
 /* Muscle activation of main_sim.py:4-53 / PyramidalSimulation.cpp:68-93 in closed form:
  * 96 values for step t, entries 96..muscleCount-1 left 0. */
 int sphmi_muscle_signal(int step, float* out, int muscleCount);

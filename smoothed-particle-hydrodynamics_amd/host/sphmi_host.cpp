@@ -313,6 +313,71 @@ int sphmi_save_configuration(const char* dir, const float* position, int count, 
   return SPH_OK;
 }
 
+// owHelper::loadConfigurationFromFile (owHelper.cpp:1674-1741), the `-l_from` playback input: the files written above.
+// The position file is "numOfElasticP\nnumOfLiquidP\n" followed by frames of numOfElasticP + numOfLiquidP rows
+// `x y z type`; the reference slurps all rows (its `while(good())` loop duplicates the last one, which the integer division
+// `rows / PARTICLE_COUNT` then drops) and serves frame `iteration` from memory.
+int sphmi_trajectory_info(const char* dir, int* numOfElasticP, int* numOfLiquidP, int* frames, int* numOfMembranes) {
+  if (!dir) return SPH_ERR_INVALID;
+  const std::string base = std::string(dir) + "/";
+  std::ifstream positionFile((base + "position_buffer.txt").c_str());
+  if (!positionFile.is_open()) return SPH_ERR_INVALID;
+  int ne = 0, nl = 0;
+  positionFile >> ne >> nl;
+  if (!positionFile.good() || ne < 0 || nl < 0 || ne + nl <= 0) return SPH_ERR_INVALID;
+  long long rows = 0;
+  float x, y, z, t;
+  while (positionFile >> x >> y >> z >> t) rows++;
+  if (numOfElasticP) *numOfElasticP = ne;
+  if (numOfLiquidP) *numOfLiquidP = nl;
+  if (frames) *frames = (int)(rows / (ne + nl));
+  if (numOfMembranes) {
+    *numOfMembranes = 0;
+    std::ifstream membranesFile((base + "membranes_buffer.txt").c_str());
+    if (membranesFile.is_open()) membranesFile >> *numOfMembranes;
+  }
+  return SPH_OK;
+}
+
+int sphmi_trajectory_frame(const char* dir, int frame, float* position) {
+  int ne = 0, nl = 0, frames = 0;
+  int rc = sphmi_trajectory_info(dir, &ne, &nl, &frames, nullptr);
+  if (rc != SPH_OK) return rc;
+  if (!position || frame < 0 || frame >= frames) return SPH_ERR_INVALID;
+  std::ifstream positionFile((std::string(dir) + "/position_buffer.txt").c_str());
+  int a, b;
+  positionFile >> a >> b;
+  const long long P = (long long)ne + nl, skip = P * frame;
+  float v[4];
+  for (long long i = 0; i < skip + P; i++) {
+    if (!(positionFile >> v[0] >> v[1] >> v[2] >> v[3])) return SPH_ERR_SIZE;
+    if (i >= skip) memcpy(position + 4 * (i - skip), v, sizeof(v));
+  }
+  return SPH_OK;
+}
+
+int sphmi_trajectory_connections(const char* dir, int numOfElasticP, float* connections) {
+  if (!dir || !connections || numOfElasticP <= 0) return SPH_ERR_INVALID;
+  std::ifstream connectionFile((std::string(dir) + "/connection_buffer.txt").c_str());
+  if (!connectionFile.is_open()) return SPH_ERR_INVALID;
+  const long long n = (long long)SPH_MAX_NEIGHBOR_COUNT * numOfElasticP;
+  for (long long i = 0; i < n; i++)
+    if (!(connectionFile >> connections[4 * i] >> connections[4 * i + 1] >> connections[4 * i + 2] >> connections[4 * i + 3])) return SPH_ERR_SIZE;
+  return SPH_OK;
+}
+
+int sphmi_trajectory_membranes(const char* dir, int numOfMembranes, int32_t* membranes) {
+  if (!dir || !membranes || numOfMembranes <= 0) return SPH_ERR_INVALID;
+  std::ifstream membranesFile((std::string(dir) + "/membranes_buffer.txt").c_str());
+  int count = 0;
+  if (!membranesFile.is_open() || !(membranesFile >> count) || count < numOfMembranes) return SPH_ERR_INVALID;
+  for (int i = 0; i < numOfMembranes; i++) {  // rows of four ints as the reference reads them (i, j, k, unused)
+    int32_t* m = membranes + 4 * (size_t)i;
+    if (!(membranesFile >> m[0] >> m[1] >> m[2] >> m[3])) return SPH_ERR_SIZE;
+  }
+  return SPH_OK;
+}
+
 int sphmi_muscle_signal(int step, float* out, int muscleCount) {
   if (!out || muscleCount < 96) return SPH_ERR_INVALID;
   for (int i = 0; i < muscleCount; i++) out[i] = 0.f;

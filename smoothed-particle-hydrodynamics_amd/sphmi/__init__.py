@@ -68,6 +68,10 @@ def host_lib():
         L.sphmi_generate_box.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
         L.sphmi_muscle_signal.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.sphmi_trajectory_info.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4
+        L.sphmi_trajectory_frame.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.sphmi_trajectory_connections.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.sphmi_trajectory_membranes.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
         L.sphmi_worm_counts.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double] + [C.POINTER(C.c_int)] * 4
         L.sphmi_generate_worm.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 5
         L.sphmi_save_configuration.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -91,7 +95,8 @@ EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sp
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
                          "sphmi_generate_box", "sphmi_muscle_signal", "sphmi_save_configuration", "sphmi_worm_counts",
-                         "sphmi_generate_worm"]
+                         "sphmi_generate_worm", "sphmi_trajectory_info", "sphmi_trajectory_frame", "sphmi_trajectory_connections",
+                         "sphmi_trajectory_membranes"]
 
 
 def device_lib():
@@ -228,6 +233,31 @@ def save_configuration(directory, position, num_elastic, num_liquid, connections
                                              0 if mem is None else mem.shape[0], int(first))
     if rc:
         raise SphError("sphmi_save_configuration failed: %d" % rc)
+
+
+def load_trajectory(directory):
+    """owHelper::loadConfigurationFromFile (owHelper.cpp:1674-1741): read back a `-l_to` dump. Returns a dict with
+    numOfElasticP, numOfLiquidP, frames[F, P, 4] and, when present, connections[32*E, 4] and membranes[M, 4]."""
+    L = host_lib()
+    ne, nl, nf, nm = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    d = directory.encode()
+    if L.sphmi_trajectory_info(d, C.byref(ne), C.byref(nl), C.byref(nf), C.byref(nm)):
+        raise SphError("no trajectory in %s" % directory)
+    P = ne.value + nl.value
+    frames = np.empty((nf.value, P, 4), np.float32)
+    for f in range(nf.value):
+        if L.sphmi_trajectory_frame(d, f, frames[f].ctypes.data):
+            raise SphError("trajectory frame %d unreadable" % f)
+    out = dict(numOfElasticP=ne.value, numOfLiquidP=nl.value, frames=frames, connections=None, membranes=None)
+    if ne.value:
+        con = np.empty((32 * ne.value, 4), np.float32)
+        if L.sphmi_trajectory_connections(d, ne.value, con.ctypes.data) == 0:
+            out["connections"] = con
+    if nm.value:
+        mem = np.empty((nm.value, 4), np.int32)
+        if L.sphmi_trajectory_membranes(d, nm.value, mem.ctypes.data) == 0:
+            out["membranes"] = mem
+    return out
 
 
 def muscle_signal(step, muscle_count=100):

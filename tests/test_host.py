@@ -105,6 +105,28 @@ def test_trajectory_dump_format(tmp_path):
     assert int(mem[0]) == sc["membranes"].shape[0] and [int(v) for v in mem[1].split("\t")] == list(sc["membranes"][0]) + [0]
 
 
+def test_trajectory_playback_reader_roundtrip(tmp_path):
+    """owHelper::loadConfigurationFromFile (owHelper.cpp:1674-1741): the `-l_from` reader gets back what the `-l_to` writer
+    dumped — counts, frame count, every row to the 6 significant digits the text holds, connections and membranes."""
+    sc = scenes.SCENES["tiny_elastic"]()
+    n_el, n_liq = sc["numOfElasticP"], sc["numOfLiquidP"]
+    moved = sc["position"].copy()
+    moved[:, :3] += np.float32(0.125)
+    sphmi.save_configuration(str(tmp_path), sc["position"], n_el, n_liq, sc["elastic"], sc["membranes"], first=True)
+    sphmi.save_configuration(str(tmp_path), moved, n_el, n_liq, first=False)
+    sphmi.save_configuration(str(tmp_path), sc["position"], n_el, n_liq, first=False)
+    tr = sphmi.load_trajectory(str(tmp_path))
+    assert (tr["numOfElasticP"], tr["numOfLiquidP"]) == (n_el, n_liq) and tr["frames"].shape == (3, n_el + n_liq, 4)
+    keep = sc["position"][:, 3].astype(np.int32) != 3
+    np.testing.assert_allclose(tr["frames"][0], sc["position"][keep], rtol=1e-5)
+    np.testing.assert_allclose(tr["frames"][1], moved[keep], rtol=1e-5)
+    assert np.array_equal(tr["frames"][2], tr["frames"][0])
+    np.testing.assert_allclose(tr["connections"], sc["elastic"], rtol=1e-5)
+    assert np.array_equal(tr["membranes"][:, :3], sc["membranes"]) and np.all(tr["membranes"][:, 3] == 0)
+    with pytest.raises(sphmi.SphError):
+        sphmi.load_trajectory(str(tmp_path / "missing"))
+
+
 def test_muscle_signal_matches_reference_generator():
     """sphmi_muscle_signal against values produced by the reference's own main_sim.py (fixture
     tests/golden/muscle_signal.npz, generated by tests/golden/make_muscle_golden.py), narrowed to float as
