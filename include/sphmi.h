@@ -164,6 +164,13 @@ int sph_slab_pack_framed(sph_solver* s, void* frameDown, void* frameUp, int32_t 
  * received messages must be in ascending global-id order, as sph_slab_pack writes them; a message that is not makes the
  * next sph_slab_pack fail with SPH_ERR_INVALID). */
 int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp);
+/* Overlapped variant of "sph_step, then sph_slab_pack_framed": sph_slab_step_begin enqueues the whole step with its last stage
+ * (pressure force + integrate) running first on the owned layers next to the cuts, packs the two frames as soon as those are
+ * integrated, and returns without waiting; sph_slab_step_messages blocks only until the frames are ready and gives the
+ * record counts (down, up) — the caller can hand the frames to RCCL while the rest of the step is still running; the following
+ * sph_slab_rebuild waits for the step and takes the kept count from it. capRecords overflow is reported by sph_slab_step_messages. */
+int sph_slab_step_begin(sph_solver* s, int iterationCount, void* frameDown, void* frameUp, int32_t capRecords);
+int sph_slab_step_messages(sph_solver* s, int32_t counts[2]);
 int sph_particle_count(sph_solver* s);
 /* Blocking read of the local set in its current order: positions, velocities (4 floats each), global ids and the
  * ownership flag (1 = in the owned layers when the set was last rebuilt); arrays sized sph_particle_count(). */

@@ -54,6 +54,16 @@ SphDev sph_ranged(const sph_solver* s, int ghostDepth) {
   return d;
 }
 
+SphDev sph_ranged_layers(const sph_solver* s, long long lo, long long hi) {
+  SphDev d = s->d;
+  const long long layerCells = (long long)d.gx * d.gy;
+  if (lo < 0) lo = 0;
+  if (hi > d.gz) hi = d.gz;
+  if (hi < lo) hi = lo;
+  d.rangeLo = (int)(lo * layerCells); d.rangeHi = (int)(hi * layerCells);
+  return d;
+}
+
 static int bit_length(uint32_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
 // Radial-histogram bin of a squared distance exactly as findNeighbors computes it (sphFluid.cl:159-160):
@@ -153,6 +163,8 @@ static void free_all(sph_solver* s) {
                   d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
                   s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (s->slabHost) hipHostFree(s->slabHost);
+  if (s->slabMsgEvent) hipEventDestroy(s->slabMsgEvent);
   if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
   free(s->pending);
   free(s->hostScratch);
@@ -254,7 +266,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.nbrId, mapN); A(d.nbrDist, mapN);
   A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
   A(s->blockHist, (size_t)256 * s->maxSortBlocks + 256);  // [256][maxSortBlocks] block histograms + 256 digit totals
-  A(d.gid, n); A(d.owned, n); A(s->slabCounts, 4);
+  A(d.gid, n); A(d.owned, n); A(s->slabCounts, 12);
   A(d.dbg, 16);
   float* binU = nullptr;
   A(binU, 32);
@@ -433,9 +445,15 @@ extern "C" int sph_run_compute_interaction_with_membranes_finalize(sph_solver* s
 //   (forces for iteration 0, pressure force for the later ones); correctPressure folded into predictDensity;
 //   integrate folded into the last pressure-force kernel; membrane kernels skipped when there is no elastic matter
 //   (their only effect, `position += 0`, is applied in integrate).
-extern "C" int sph_step(sph_solver* s, int iterationCount) {
-  (void)iterationCount;
-  ENTER(s);
+// The launches of one fused step, in order, on s->stream. `tail` (slab mode, overlapped step only): the last stage —
+// pressure force + integrate, the only one whose results the halo messages carry — is launched first on the owned layers
+// next to the cuts, then the messages are packed (tail->packMessages), then the remaining owned layers follow.
+struct StepTail {
+  uint32_t *frameDown, *frameUp;
+  int capRecords;
+};
+
+static int enqueue_step(sph_solver* s, const StepTail* tail) {
   int rc;
 #define RUN(stage, call) do { StageTimer t_(s, stage); rc = (call); if (rc != SPH_OK) return rc; } while (0)
   RUN(SPH_ST_HASH, sphk_hash(s));
@@ -457,7 +475,29 @@ extern "C" int sph_step(sph_solver* s, int iterationCount) {
   for (int iter = 0; iter < M; iter++) {
     const int left = M - 1 - iter;  // iterations after this one
     RUN(SPH_ST_PREDICT_DENSITY, sphk_predict_density(s, true, layersFor(2 * left + 1)));
-    RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force(s, left == 0 ? 2 : 1, layersFor(2 * left)));
+    if (left > 0 || !tail) { RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force(s, left == 0 ? 2 : 1, layersFor(2 * left))); continue; }
+    // ---- overlapped tail. A particle that ends the step within W layers of a cut started it within W + 1 layers (particles
+    // move less than one layer per step — the same assumption the ghost depth rests on), so integrating the W + 1 owned
+    // layers next to each cut first makes every message particle final; the pack below only looks at those.
+    const long long lo = max((long long)s->slab.layerLo, 0LL), hi = min((long long)s->slab.layerHi, (long long)s->d.gz);
+    const long long W1 = (long long)s->slab.ghostLayers + 1;
+    const long long dEnd = s->slab.hasLower ? min(lo + W1, hi) : lo;         // [lo, dEnd): next to the lower cut
+    const long long uBeg = s->slab.hasUpper ? max(hi - W1, dEnd) : hi;       // [uBeg, hi): next to the upper cut
+    if (dEnd > lo) RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force_layers(s, 2, lo, dEnd));
+    if (hi > uBeg) RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force_layers(s, 2, uBeg, hi));
+    const SphDev dA = sph_ranged_layers(s, lo, dEnd), dB = sph_ranged_layers(s, uBeg, hi);
+    // (cell ranges: the pack kernel turns them into sorted-index ranges with the cell table, which lives on the device)
+    SlabPart part{SLAB_PART_MESSAGES, dA.rangeLo, dA.rangeHi, dB.rangeLo, dB.rangeHi};
+    rc = sphk_slab_pack(s, tail->frameDown ? tail->frameDown + 1 : nullptr, tail->frameUp ? tail->frameUp + 1 : nullptr, tail->capRecords,
+                        tail->frameDown, tail->frameUp, part, s->slabCounts + 4);
+    if (rc != SPH_OK) return rc;
+    SPH_HIP(hipMemcpyAsync(s->slabHost + 4, s->slabCounts + 4, sizeof(uint32_t) * 3, hipMemcpyDeviceToHost, s->stream));
+    SPH_HIP(hipEventRecord(s->slabMsgEvent, s->stream));
+    if (uBeg > dEnd) RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force_layers(s, 2, dEnd, uBeg));
+    rc = sphk_slab_pack(s, nullptr, nullptr, 0, nullptr, nullptr, SlabPart{SLAB_PART_KEPT, 0, 0, 0, 0}, s->slabCounts + 8);
+    if (rc != SPH_OK) return rc;
+    SPH_HIP(hipMemcpyAsync(s->slabHost + 8, s->slabCounts + 8, sizeof(uint32_t) * 3, hipMemcpyDeviceToHost, s->stream));
+    SPH_HIP(hipMemcpyAsync(s->slabHost + 3, s->slabCounts + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   }
   if (s->d.hasElastic) {
     RUN(SPH_ST_MEMBRANES, sphk_clear_membranes(s));
@@ -468,6 +508,12 @@ extern "C" int sph_step(sph_solver* s, int iterationCount) {
   s->progress = P_HASH | P_SORT | P_SORTPOST | P_INDEXPOST | P_FIND | P_DENSITY | P_FORCES | P_PREDICTPOS | P_PREDICTDENS |
                 P_PRESSUREFORCE;
   return SPH_OK;
+}
+
+extern "C" int sph_step(sph_solver* s, int iterationCount) {
+  (void)iterationCount;
+  ENTER(s);
+  return enqueue_step(s, nullptr);
 }
 
 extern "C" int sph_update_muscles(sph_solver* s, const float* signal, int n) {
@@ -618,13 +664,15 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
     sph_set_error("ghostLayers = %d is too thin for maxIteration = %d", slab->ghostLayers, s->cfg.maxIteration);
     return SPH_ERR_INVALID;
   }
-  s->slab = *slab; s->hasSlab = true; s->slabKept = -1;
+  s->slab = *slab; s->hasSlab = true; s->slabKept = -1; s->slabStepPending = false;
+  if (!s->slabHost) SPH_HIP(hipHostMalloc((void**)&s->slabHost, sizeof(uint32_t) * 12, hipHostMallocDefault));
+  if (!s->slabMsgEvent) SPH_HIP(hipEventCreateWithFlags(&s->slabMsgEvent, hipEventDisableTiming));
   SPH_HIP(hipMemcpyAsync(s->d.gid, globalIds, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyHostToDevice, s->stream));
   // ownership flags from the initial positions: reuse the rebuild path with nothing received
   SPH_HIP(hipMemcpyAsync(s->d.sortedPos, s->d.posOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
   SPH_HIP(hipMemcpyAsync(s->d.sortedVel, s->d.velOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
   SPH_HIP(hipMemcpyAsync(s->d.keys, s->d.gid, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
-  SPH_HIP(hipMemsetAsync(s->slabCounts, 0, sizeof(uint32_t) * 4, s->stream));
+  SPH_HIP(hipMemsetAsync(s->slabCounts, 0, sizeof(uint32_t) * 12, s->stream));
   int rc = sphk_slab_sort_rebuild(s, s->d.N);
   if (rc != SPH_OK) return rc;
   SPH_HIP(hipStreamSynchronize(s->stream));
@@ -665,9 +713,48 @@ extern "C" int sph_slab_pack_framed(sph_solver* s, void* frameDown, void* frameU
   return slab_pack(s, fd ? fd + 1 : nullptr, fu ? fu + 1 : nullptr, capRecords, counts, fd, fu);
 }
 
+// ---- overlapped step: sph_slab_step_begin enqueues everything and returns; sph_slab_step_messages blocks only until the
+// messages are packed (the rest of the step is still running); sph_slab_rebuild then waits for the step itself.
+extern "C" int sph_slab_step_begin(sph_solver* s, int iterationCount, void* frameDown, void* frameUp, int32_t capRecords) {
+  (void)iterationCount;
+  ENTER(s);
+  if (!s->hasSlab || capRecords < 0 || (s->slab.hasLower && !frameDown) || (s->slab.hasUpper && !frameUp)) {
+    sph_set_error("sph_slab_step_begin: slab not initialised or null frame buffer"); return SPH_ERR_INVALID; }
+  if (s->slabStepPending) { sph_set_error("sph_slab_step_begin: the previous overlapped step was not rebuilt"); return SPH_ERR_ORDER; }
+  StepTail tail{(uint32_t*)frameDown, (uint32_t*)frameUp, (int)capRecords};
+  const int rc = enqueue_step(s, &tail);
+  if (rc != SPH_OK) return rc;
+  s->slabStepPending = true;
+  s->slabKept = -1;
+  s->slabCapRecords = (int)capRecords;
+  return SPH_OK;
+}
+
+extern "C" int sph_slab_step_messages(sph_solver* s, int32_t counts[2]) {
+  ENTER(s);
+  if (!s->hasSlab || !s->slabStepPending || !counts) { sph_set_error("sph_slab_step_messages without sph_slab_step_begin"); return SPH_ERR_ORDER; }
+  SPH_HIP(hipEventSynchronize(s->slabMsgEvent));
+  counts[0] = (int32_t)s->slabHost[5]; counts[1] = (int32_t)s->slabHost[6];
+  if (counts[0] > s->slabCapRecords || counts[1] > s->slabCapRecords) {
+    sph_set_error("halo message overflow: %d / %d records, room for %d", counts[0], counts[1], s->slabCapRecords);
+    return SPH_ERR_SIZE;
+  }
+  return SPH_OK;
+}
+
 extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const void* recvUp, int32_t nUp) {
   ENTER(s);
   if (!s->hasSlab || nDown < 0 || nUp < 0 || (nDown && !recvDown) || (nUp && !recvUp)) { sph_set_error("sph_slab_rebuild: bad arguments"); return SPH_ERR_INVALID; }
+  if (s->slabStepPending) {  // overlapped step: the kept count arrives with the end of the step
+    SPH_HIP(hipStreamSynchronize(s->stream));
+    s->slabStepPending = false;
+    if (s->slabHost[3]) {
+      SPH_HIP(hipMemsetAsync(s->slabCounts + 3, 0, sizeof(uint32_t), s->stream));
+      sph_set_error("a halo message passed to the last sph_slab_rebuild was not sorted by global id");
+      return SPH_ERR_INVALID;
+    }
+    s->slabKept = (int)s->slabHost[8];
+  }
   if (s->slabKept < 0) { sph_set_error("sph_slab_rebuild without a preceding sph_slab_pack"); return SPH_ERR_ORDER; }
   const int kept = s->slabKept;
   s->slabKept = -1;

@@ -73,7 +73,12 @@ struct sph_solver {
   int capacity;              // particles the buffers are sized for (>= d.N)
   int capTiles;              // ceil(capacity/64)
   sph_slab slab; bool hasSlab;
-  uint32_t* slabCounts;      // device: kept / down / up counters
+  uint32_t* slabCounts;      // device, 12 words: [0..2] kept / down / up of sph_slab_pack, [3] unsorted-message flag,
+                             // [4..6] and [8..10] the same triples of the overlapped step's message / kept passes
+  uint32_t* slabHost;        // pinned host mirror of slabCounts (overlapped step)
+  hipEvent_t slabMsgEvent;   // recorded when the messages of the overlapped step are packed
+  bool slabStepPending;      // sph_slab_step_begin issued, rebuild not yet done
+  int slabCapRecords;        // frame capacity given to sph_slab_step_begin
   int slabKept;              // host copy of the kept count of the last sph_slab_pack (-1: none pending)
   // radix-sort workspace
   uint32_t* blockHist;       // [256][maxSortBlocks] block histograms + 256 digit totals
@@ -144,8 +149,16 @@ int sphk_correct_pressure(sph_solver* s);
 int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth = -1);  // 0 none, 1 + predictPositions, 2 + integrate
 int sphk_integrate(sph_solver* s);
 // sph_slab.hip
+// Which part of the pack a launch does. ALL: kept set + both messages (sph_slab_pack). The overlapped step packs the MESSAGES
+// as soon as the particles near the cuts (CELL ranges [a0,a1) and [b0,b1) of the sorted order) are integrated, and the KEPT set
+// at the end.
+enum { SLAB_PART_ALL = 0, SLAB_PART_MESSAGES = 1, SLAB_PART_KEPT = 2 };
+struct SlabPart { int mode, a0, a1, b0, b1; };
 int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords, uint32_t* headDown = nullptr,
-                   uint32_t* headUp = nullptr);  // head*: where to store the payload word count of each message (framed mode)
+                   uint32_t* headUp = nullptr,  // head*: where to store the payload word count of each message (framed mode)
+                   SlabPart part = SlabPart{SLAB_PART_ALL, 0, 0, 0, 0}, uint32_t* counts = nullptr);  // counts: 3 device words (default slabCounts)
+SphDev sph_ranged_layers(const sph_solver* s, long long loLayer, long long hiLayer);  // launch restricted to cell layers [lo, hi)
+int sphk_pressure_force_layers(sph_solver* s, int fuse, long long loLayer, long long hiLayer);
 int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept);  // 3-way merge
 int sphk_slab_sort_rebuild(sph_solver* s, int total);  // staging area in any order -> local set sorted by global id
 // sph_elastic.hip

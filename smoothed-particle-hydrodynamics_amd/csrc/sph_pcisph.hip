@@ -451,12 +451,17 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   if (FUSE == 2) integrate_particle(d, id, xi, d.sortedVel[id], d.acc[id], ap);
 }
 
-int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth) {
+static int launch_pressure_force(sph_solver* s, int fuse, const SphDev& d) {
   const int nb = sph_blocks(s->d.N);
-  const SphDev d = sph_ranged(s, ghostDepth);
   if (fuse == 0) hipLaunchKernelGGL((k_pressure_force<0>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   else if (fuse == 1) hipLaunchKernelGGL((k_pressure_force<1>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   else hipLaunchKernelGGL((k_pressure_force<2>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
+}
+
+int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth) { return launch_pressure_force(s, fuse, sph_ranged(s, ghostDepth)); }
+
+int sphk_pressure_force_layers(sph_solver* s, int fuse, long long loLayer, long long hiLayer) {
+  return launch_pressure_force(s, fuse, sph_ranged_layers(s, loLayer, hiLayer));
 }

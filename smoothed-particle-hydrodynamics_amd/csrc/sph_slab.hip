@@ -26,21 +26,34 @@ __device__ __forceinline__ void put_record(uint32_t* msg, uint32_t j, const floa
 template <bool WRITE>
 __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab, uint32_t* __restrict__ blockCounts,
                                                          const uint32_t* __restrict__ blockOffsets, uint32_t* __restrict__ msgDown,
-                                                         uint32_t* __restrict__ msgUp, int capRecords) {
+                                                         uint32_t* __restrict__ msgUp, int capRecords, SlabPart part) {
   __shared__ uint32_t tot[PACK_ITEMS * (SPH_BLOCK / 64)][3];  // hits per (round, wave), then their exclusive prefix
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int first = blockIdx.x * PACK_SPAN + tid;
+  int a0 = 0, a1 = 0, b0 = 0, b1 = 0;  // messages-only pass: sorted-index ranges of the particles integrated so far
+  if (part.mode == SLAB_PART_MESSAGES) {
+    a0 = (int)d.cellStart[part.a0]; a1 = (int)d.cellStart[part.a1]; b0 = (int)d.cellStart[part.b0]; b1 = (int)d.cellStart[part.b1];
+  }
   uint32_t flags[PACK_ITEMS], rank[PACK_ITEMS];  // bit c: goes to destination c; 10 bits of rank per destination
 #pragma unroll
   for (int u = 0; u < PACK_ITEMS; u++) {  // element order inside the workgroup: (round u, thread) = ascending particle index
     const int i = first + u * SPH_BLOCK;
     uint32_t f = 0u;
     if (i < d.N && d.owned[i]) {
-      const int layer = (int)(d.posOrig[i].z * d.cellSizeInv);  // the z cell coordinate hashParticles uses (sphFluid.cl:199)
-      f = 1u;
-      if (slab.hasLower && layer < slab.layerLo + slab.ghostLayers) f |= 2u;
-      if (slab.hasUpper && layer >= slab.layerHi - slab.ghostLayers) f |= 4u;
+      bool final_ = true;  // messages-only pass of the overlapped step: only particles that have been integrated already
+      if (part.mode == SLAB_PART_MESSAGES) {
+        const int sid = (int)d.backIndex[i];
+        final_ = (sid >= a0 && sid < a1) || (sid >= b0 && sid < b1);
+      }
+      if (final_) {
+        const int layer = (int)(d.posOrig[i].z * d.cellSizeInv);  // the z cell coordinate hashParticles uses (sphFluid.cl:199)
+        if (part.mode != SLAB_PART_MESSAGES) f = 1u;
+        if (part.mode != SLAB_PART_KEPT) {
+          if (slab.hasLower && layer < slab.layerLo + slab.ghostLayers) f |= 2u;
+          if (slab.hasUpper && layer >= slab.layerHi - slab.ghostLayers) f |= 4u;
+        }
+      }
     }
     flags[u] = f;
     uint32_t r = 0u;
@@ -65,13 +78,15 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab
 #pragma unroll
   for (int u = 0; u < PACK_ITEMS; u++) {
     const uint32_t f = flags[u];
-    if (!(f & 1u)) continue;
+    if (!f) continue;
     const int i = first + u * SPH_BLOCK;
     const int g = u * (SPH_BLOCK / 64) + wave;
     const float4 p = d.posOrig[i], v = d.velOrig[i];
     const uint32_t gid = d.gid[i];
-    const uint32_t k = base0 + tot[g][0] + (rank[u] & 1023u);
-    d.sortedPos[k] = p; d.sortedVel[k] = v; d.keys[k] = gid;  // sorted* / keys are free between two steps: staging area
+    if (f & 1u) {
+      const uint32_t k = base0 + tot[g][0] + (rank[u] & 1023u);
+      d.sortedPos[k] = p; d.sortedVel[k] = v; d.keys[k] = gid;  // sorted* / keys are free between two steps: staging area
+    }
     if (f & 2u) { const uint32_t j = base1 + tot[g][1] + ((rank[u] >> 10) & 1023u); if ((int)j < capRecords) put_record(msgDown, j, p, v, gid); }
     if (f & 4u) { const uint32_t j = base2 + tot[g][2] + ((rank[u] >> 20) & 1023u); if ((int)j < capRecords) put_record(msgUp, j, p, v, gid); }
   }
@@ -113,13 +128,15 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_scan(const uint32_t* __restr
   if (tid == 2 && headUp) *headUp = carry[2] * REC;
 }
 
-int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords, uint32_t* headDown, uint32_t* headUp) {
+int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords, uint32_t* headDown, uint32_t* headUp,
+                   SlabPart part, uint32_t* counts) {
   const int nb = sph_blocks(s->d.N, PACK_SPAN);
   uint32_t* blockCounts = s->blockHist;  // the radix-sort workspace is idle between two steps: >= capacity/16 words
   uint32_t* blockOffsets = s->blockHist + (size_t)nb * 4;
-  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords);
-  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, s->slabCounts, headDown, headUp);
-  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords);
+  if (!counts) counts = s->slabCounts;
+  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part);
+  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, counts, headDown, headUp);
+  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }

@@ -90,7 +90,7 @@ _STAGE_FUNCS = ["sph_run_clear_buffers", "sph_run_hash_particles", "sph_run_sort
 EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sph_step", "sph_update_muscles",
                     "sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index",
                     "sph_read_buffer", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
-                    "sph_reset_stage_times", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed",
+                    "sph_reset_stage_times", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed", "sph_slab_step_begin", "sph_slab_step_messages",
                     "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
@@ -129,6 +129,8 @@ def device_lib():
         L.sph_slab_init.argtypes = [C.c_void_p, C.POINTER(SphSlab), C.c_void_p]
         L.sph_slab_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.sph_slab_pack_framed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.sph_slab_step_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32]
+        L.sph_slab_step_messages.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.sph_slab_rebuild.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.sph_particle_count.argtypes = [C.c_void_p]
         L.sph_slab_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -388,6 +390,14 @@ class owHIPSolver:
         counts = (C.c_int32 * 3)()
         self._chk(self._L.sph_slab_pack_framed(self._h, frame_down_ptr, frame_up_ptr, cap_records, counts))
         return counts[0], counts[1], counts[2]
+
+    def slab_step_begin(self, iterationCount, frame_down_ptr, frame_up_ptr, cap_records):
+        self._chk(self._L.sph_slab_step_begin(self._h, iterationCount, frame_down_ptr, frame_up_ptr, cap_records))
+
+    def slab_step_messages(self):
+        counts = (C.c_int32 * 2)()
+        self._chk(self._L.sph_slab_step_messages(self._h, counts))
+        return counts[0], counts[1]
 
     def slab_rebuild(self, recv_down_ptr, n_down, recv_up_ptr, n_up):
         self._chk(self._L.sph_slab_rebuild(self._h, recv_down_ptr, n_down, recv_up_ptr, n_up))

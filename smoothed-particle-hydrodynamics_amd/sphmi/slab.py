@@ -97,6 +97,14 @@ class HipSlabBackend:
     def step(self, iteration):
         self.solver.step(iteration)
 
+    def step_and_pack_framed(self, iteration):
+        """The overlapped form of step() + pack_framed(): returns as soon as the two frames are packed; the rest of the step
+        (the interior's last stage, the kept set) is still running and is waited for by rebuild(). kept is not known yet."""
+        self.solver.slab_step_begin(iteration, C.c_void_p(self.frame_down.data_ptr()), C.c_void_p(self.frame_up.data_ptr()),
+                                    self.cap_records)
+        nd, nu = self.solver.slab_step_messages()
+        return None, self.frame_down, nd * SLAB_RECORD_WORDS, self.frame_up, nu * SLAB_RECORD_WORDS
+
     def pack_framed(self):
         """(kept, frame_down, payload words, frame_up, payload words): frames ready to be sent from word 0."""
         kept, nd, nu = self.solver.slab_pack_framed(C.c_void_p(self.frame_down.data_ptr()), C.c_void_p(self.frame_up.data_ptr()),
@@ -143,6 +151,9 @@ class SlabDecomposition:
         self.bytes_sent = 0
         self.transfers = 0          # batched point-to-point groups issued so far (1 per step in steady state)
         self._bound_out, self._bound_in, self._frames = {}, {}, {}
+        # overlap the exchange with the tail of the step (sph_slab_step_begin); SPHMI_SLAB_OVERLAP=0 restores step-then-pack
+        import os
+        self.overlap = os.environ.get("SPHMI_SLAB_OVERLAP", "1") != "0"
 
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
@@ -179,16 +190,18 @@ class SlabDecomposition:
             # on the solver's own stream
             self.torch.cuda.synchronize(self.comm_device)
 
-    def exchange(self):
+    def exchange(self, prepacked=None):
         torch = self.torch
         # Zero-copy framing when the backend keeps [count | payload] frames on the communication device (HipSlabBackend under
         # RCCL): the frame is sent as it is. Otherwise (CPU-staged tests, other backends) frames are assembled here.
         zero_copy = hasattr(self.backend, "pack_framed") and getattr(self.backend, "frame_device", None) == self.comm_device
-        if zero_copy:
-            kept, frame_down, nd, frame_up, nu = self.backend.pack_framed()
+        if prepacked is not None or zero_copy:
+            kept, frame_down, nd, frame_up, nu = prepacked if prepacked is not None else self.backend.pack_framed()
             frames = {self.lower: frame_down, self.upper: frame_up}
             n_words = {self.lower: nd, self.upper: nu}
             payload = None
+            if not zero_copy:  # frames live on another device than the communication runs on (CPU-staged tests)
+                payload = {p: f[1:1 + n_words[p]] for p, f in frames.items()}
         else:
             kept, msg_down, msg_up = self.backend.pack()
             payload = {self.lower: msg_down, self.upper: msg_up}
@@ -245,6 +258,11 @@ class SlabDecomposition:
 
     def step(self, iteration):
         import time
+        if self.overlap and self.world > 1 and hasattr(self.backend, "step_and_pack_framed"):
+            t0 = time.perf_counter()  # (includes the wait for the step itself up to the packed messages)
+            n = self.exchange(self.backend.step_and_pack_framed(iteration))
+            self.exchange_seconds = getattr(self, "exchange_seconds", 0.0) + time.perf_counter() - t0
+            return n
         self.backend.step(iteration)
         t0 = time.perf_counter()
         n = self.exchange()

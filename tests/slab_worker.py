@@ -23,6 +23,8 @@ REC = sphmi.SLAB_RECORD_WORDS
 
 def scene():
     # wide-mode box, long in z: 30 cell layers, lattice with a little jitter so that particles cross the cut
+    if os.environ.get("SPHMI_TEST_LONG_SCENE"):  # 42 layers: three slabs of 14, so the middle one has an interior between its two cut zones
+        return scenes.liquid_box((8.0, 8.0, 84.0), (12, 10, 156), mask=0xffffffff, jitter_in_r0=0.05)
     return scenes.liquid_box((8.0, 8.0, 60.0), (12, 10, 110), mask=0xffffffff, jitter_in_r0=0.05)
 
 

@@ -39,10 +39,15 @@ def run_ranks(backend, world, out, steps=STEPS, env=None):
     return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
 
 
-def single_domain_reference(steps=STEPS):
+def single_domain_reference(steps=STEPS, long_scene=False):
     sys.path.insert(0, HERE)
     import slab_worker
-    sc = slab_worker.scene()
+    if long_scene:
+        os.environ["SPHMI_TEST_LONG_SCENE"] = "1"
+    try:
+        sc = slab_worker.scene()
+    finally:
+        os.environ.pop("SPHMI_TEST_LONG_SCENE", None)
     o = scenes.oracle_for(sc, threads=8)
     for _ in range(steps):
         o.step()
@@ -124,6 +129,19 @@ def test_three_rank_halo_exchange_matches_single_domain_gpu(tmp_path):
     sc, pos_ref, vel_ref = single_domain_reference(steps=6)
     check_union(results, sc, pos_ref, vel_ref)
     assert all(int(r["transfers"]) == 6 + 1 for r in results)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_three_rank_long_scene_overlapped_and_plain_step_gpu(tmp_path, overlap):
+    """Slabs of 14 layers: the middle rank integrates two cut zones of 5 layers first, packs, then its 4 interior layers
+    (sph_slab_step_begin); with SPHMI_SLAB_OVERLAP=0 the plain step-then-pack path. Both bit-identical to the single domain."""
+    env = {"SPHMI_TEST_LONG_SCENE": "1", "SPHMI_SLAB_OVERLAP": overlap}
+    results = run_ranks("hip", 3, tmp_path, steps=5, env=env)
+    sc, pos_ref, vel_ref = single_domain_reference(steps=5, long_scene=True)
+    check_union(results, sc, pos_ref, vel_ref)
+    cuts = results[1]["cuts"]
+    assert cuts[2] - cuts[1] >= 11, "the middle slab must be thicker than its two cut zones"
 
 
 @pytest.mark.gpu
