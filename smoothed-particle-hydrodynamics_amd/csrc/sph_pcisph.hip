@@ -35,6 +35,22 @@ struct NbrTile {
 
 // XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs; remap so that each
 // XCD works on one contiguous eighth of the sorted particle range and its L2 holds only that slab's neighbourhood.
+// Range-aware form for launches restricted to a cell range (slab mode): the remap must run over the blocks that HAVE work.
+// Remapping over the whole grid would hand the first eighth of the logical blocks — for a short range, all of the work — to
+// one XCD (a 5-layer launch then took as long as the full one: 120 us instead of 17).
+__device__ __forceinline__ bool xcd_range_id(const SphDev& d, int& id) {
+  const int begin = (int)d.cellStart[d.rangeLo], end = (int)d.cellStart[d.rangeHi];
+  const int active = (end - begin + SPH_BLOCK - 1) / SPH_BLOCK;
+  int b = blockIdx.x;
+  if (b >= active) return false;
+#ifndef NO_XCD_REMAP
+  const int per = active >> 3, even = per << 3;
+  if (b < even) b = (b & 7) * per + (b >> 3);
+#endif
+  id = begin + b * SPH_BLOCK + threadIdx.x;
+  return id < end;
+}
+
 __device__ __forceinline__ int xcd_block(int nblocks) {
 #ifdef NO_XCD_REMAP
   return blockIdx.x;
@@ -130,7 +146,7 @@ int sphk_predict_positions(sph_solver* s) {
 template <bool FUSE_PREDICT>
 __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
   int id;
-  if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
+  if (!xcd_range_id(d, id)) return;
   const float4 xi = d.sortedPos[id];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
@@ -246,7 +262,7 @@ __device__ __forceinline__ float corrected_pressure(const SphDev& d, float p, fl
 template <bool FUSE_CORRECT>
 __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nblocks) {
   int id;
-  if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
+  if (!xcd_range_id(d, id)) return;
   const float4 xi = d.predPos[id];
   const NbrTile t(d, id);
   // Branch-free: all 8 id loads first, then the gathers in batches of 8 with an always-valid index (empty slots read
@@ -396,7 +412,7 @@ int sphk_integrate(sph_solver* s) {
 template <int FUSE>
 __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblocks) {
   int id;
-  if (!sph_range_id(d, xcd_block(nblocks) * SPH_BLOCK + threadIdx.x, id)) return;
+  if (!xcd_range_id(d, id)) return;
   const float4 xi = d.sortedPos[id];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
