@@ -80,6 +80,21 @@ for it in range(steps + 3):
         a, b = (None if a is None else a.clone()), (None if b is None else b.clone())
         torch.cuda.current_stream().synchronize()  # the copies run on torch's stream, the rebuild on the solver's
         backs[r].rebuild(a, b)
+if os.environ.get("SPHMI_STAGES"):  # per-stage device times of the middle slab (plain path), a few more steps
+    mid.solver.set_stage_timing(True); mid.solver.reset_stage_times()
+    k = 5
+    for it2 in range(steps + 3, steps + 3 + k):
+        frames = [produce(backs[r], it2) if r != 1 else None for r in range(world)]
+        mid.step(it2)
+        frames[1] = mid.pack_framed()
+        torch.cuda.synchronize()
+        for r in range(world):
+            a, b = received(frames, r)
+            a, b = (None if a is None else a.clone()), (None if b is None else b.clone())
+            torch.cuda.current_stream().synchronize()
+            backs[r].rebuild(a, b)
+    st = mid.solver.stage_times()
+    print("  stages (ms/step):", {n: round(ms / k, 4) for n, (ms, c) in st.items() if c})
 times = np.array(times) * 1e3
 print("  until frames ready %.3f ms, transfer emulation %.3f ms, rebuild incl. wait for the step %.3f ms" % tuple(np.array(parts).mean(0) * 1e3))
 print("interior rank: %.3f ms/step (p50 %.3f) for %d local / %d owned particles, emulated transfer delay %.0f us" % (
