@@ -34,23 +34,58 @@ def particle_layers(position, cfg):
     return (z * np.float32(cfg.hashGridCellSizeInv)).astype(np.int32)
 
 
-def balanced_cuts(layers, world, min_thickness=2 * GHOST_LAYERS):
-    """Cut the occupied layer range into `world` slabs of (nearly) equal particle count. Returns world+1 cut layers with
-    open ends; every slab must be at least 2*GHOST_LAYERS thick so that halos only ever involve direct neighbours."""
+GHOST_COST = 0.75  # what a ghost particle costs relative to an owned one (measured: 8 ghost layers of 25 add ~24 % to the step)
+
+
+def balanced_cuts(layers, world, min_thickness=2 * GHOST_LAYERS, ghost_cost=GHOST_COST):
+    """Cut the occupied layer range into `world` slabs of (nearly) equal COST = owned particles + ghost_cost x ghost particles
+    (the GHOST_LAYERS layers beyond each cut that the rank also advances): the two end slabs have one ghost zone instead of
+    two and get correspondingly more layers. Returns world+1 cut layers; every slab is at least 2*GHOST_LAYERS thick so that
+    halos only ever involve direct neighbours. Deterministic: every rank computes the same cuts from the same histogram."""
     lo, hi = int(layers.min()), int(layers.max()) + 1
     hist = np.bincount(layers - lo, minlength=hi - lo).astype(np.int64)
-    cum = np.cumsum(hist)
-    cuts = [lo]
-    for r in range(1, world):
-        target = cum[-1] * r / world
-        c = lo + int(np.searchsorted(cum, target)) + 1
-        c = max(c, cuts[-1] + min_thickness)
-        cuts.append(c)
-    cuts.append(hi)
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        if b - a < min_thickness:
-            raise ValueError("slab [%d,%d) thinner than %d layers: too many ranks for this box" % (a, b, min_thickness))
-    return cuts
+    cum = np.concatenate([[0], np.cumsum(hist)])
+
+    def count(a, b):  # particles in layers [a, b), clipped to the occupied range
+        a, b = min(max(a, lo), hi), min(max(b, lo), hi)
+        return int(cum[b - lo] - cum[a - lo]) if b > a else 0
+
+    def cost(cuts, r):
+        a, b = cuts[r], cuts[r + 1]
+        ghosts = (count(a - GHOST_LAYERS, a) if r > 0 else 0) + (count(b, b + GHOST_LAYERS) if r < world - 1 else 0)
+        return count(a, b) + ghost_cost * ghosts
+
+    def sweep(limit):
+        """Greedy left-to-right assignment with every slab's cost <= limit; None if the last slab would exceed it."""
+        cuts = [lo]
+        for r in range(world - 1):
+            a = cuts[-1]
+            b = a + min_thickness
+            if b > hi - min_thickness * (world - 1 - r):
+                return None
+            trial = cuts + [b]
+            if cost(trial + [hi] * (world - len(trial)), r) > limit:
+                return None  # even the thinnest admissible slab is too expensive
+            while b + 1 <= hi - min_thickness * (world - 1 - r) and cost(cuts + [b + 1] + [hi] * (world - len(cuts) - 1), r) <= limit:
+                b += 1
+            cuts.append(b)
+        cuts.append(hi)
+        return cuts if cost(cuts, world - 1) <= limit else None
+
+    if (hi - lo) < min_thickness * world:
+        raise ValueError("%d occupied layers are too few for %d slabs of at least %d layers" % (hi - lo, world, min_thickness))
+    lo_t, hi_t = 0.0, float(cum[-1]) * (1.0 + 2.0 * ghost_cost)
+    best = sweep(hi_t)
+    if best is None:
+        raise ValueError("no admissible slab decomposition into %d ranks" % world)
+    for _ in range(60):  # bisection on the admissible maximum cost
+        mid = 0.5 * (lo_t + hi_t)
+        c = sweep(mid)
+        if c is None:
+            lo_t = mid
+        else:
+            hi_t, best = mid, c
+    return best
 
 
 def make_slab(cuts, rank, world, n_global):

@@ -82,6 +82,19 @@ def test_partition_helpers():
     assert np.all(np.diff(idx[0].astype(np.int64)) > 0)                 # ascending global id
     with pytest.raises(ValueError):
         S.balanced_cuts(lay, 16)                                        # slabs thinner than 2 * GHOST_LAYERS
+    # cost balance: an interior slab pays for two ghost zones, an end slab for one -> the ends get more layers, and the largest
+    # cost (owned + 0.75 x ghosts) is never above what equal owned counts would give
+    def worst(cuts):
+        out = []
+        for r in range(len(cuts) - 1):
+            own = int(((lay >= cuts[r]) & (lay < cuts[r + 1])).sum())
+            gh = (int(((lay >= cuts[r] - S.GHOST_LAYERS) & (lay < cuts[r])).sum()) if r else 0) + \
+                 (int(((lay >= cuts[r + 1]) & (lay < cuts[r + 1] + S.GHOST_LAYERS)).sum()) if r < len(cuts) - 2 else 0)
+            out.append(own + S.GHOST_COST * gh)
+        return max(out)
+    c3, e3 = S.balanced_cuts(lay, 3), S.balanced_cuts(lay, 3, ghost_cost=0.0)
+    assert worst(c3) <= worst(e3)
+    assert (c3[2] - c3[1]) <= min(c3[1] - c3[0], c3[3] - c3[2])  # the middle slab is the thinnest
 
 
 def test_two_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
