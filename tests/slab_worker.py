@@ -22,6 +22,13 @@ REC = sphmi.SLAB_RECORD_WORDS
 
 
 def scene():
+    sc = _scene()
+    if os.environ.get("SPHMI_TEST_MAXITER"):  # other predict-correct iteration counts change every stage's ghost depth
+        sc["cfg"].maxIteration = int(os.environ["SPHMI_TEST_MAXITER"])
+    return sc
+
+
+def _scene():
     # wide-mode box, long in z: 30 cell layers, lattice with a little jitter so that particles cross the cut
     if os.environ.get("SPHMI_TEST_LONG_SCENE"):  # 42 layers: three slabs of 14, so the middle one has an interior between its two cut zones
         return scenes.liquid_box((8.0, 8.0, 84.0), (12, 10, 156), mask=0xffffffff, jitter_in_r0=0.05)

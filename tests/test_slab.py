@@ -39,15 +39,18 @@ def run_ranks(backend, world, out, steps=STEPS, env=None):
     return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
 
 
-def single_domain_reference(steps=STEPS, long_scene=False):
+def single_domain_reference(steps=STEPS, long_scene=False, max_iteration=None):
     sys.path.insert(0, HERE)
     import slab_worker
     if long_scene:
         os.environ["SPHMI_TEST_LONG_SCENE"] = "1"
+    if max_iteration:
+        os.environ["SPHMI_TEST_MAXITER"] = str(max_iteration)
     try:
         sc = slab_worker.scene()
     finally:
         os.environ.pop("SPHMI_TEST_LONG_SCENE", None)
+        os.environ.pop("SPHMI_TEST_MAXITER", None)
     o = scenes.oracle_for(sc, threads=8)
     for _ in range(steps):
         o.step()
@@ -155,6 +158,23 @@ def test_three_rank_long_scene_overlapped_and_plain_step_gpu(tmp_path, overlap):
     check_union(results, sc, pos_ref, vel_ref)
     cuts = results[1]["cuts"]
     assert cuts[2] - cuts[1] >= 11, "the middle slab must be thicker than its two cut zones"
+
+
+@pytest.mark.gpu
+def test_other_iteration_counts_change_the_ghost_depths_gpu(tmp_path):
+    """maxIteration = 2: every stage's ghost depth changes (4 hops instead of 6); still bit-identical to the single domain.
+    maxIteration = 4 needs 8 hops = 4.13 layers > the 4 ghost layers: sph_slab_init must refuse it."""
+    results = run_ranks("hip", 2, tmp_path, steps=4, env={"SPHMI_TEST_MAXITER": "2"})
+    sc, pos_ref, vel_ref = single_domain_reference(steps=4, max_iteration=2)
+    assert sc["cfg"].maxIteration == 2
+    check_union(results, sc, pos_ref, vel_ref)
+    sc4 = scenes.liquid_box((8.0, 8.0, 20.0), (12, 10, 30), mask=0xffffffff)
+    sc4["cfg"].maxIteration = 4
+    n = sc4["cfg"].particleCount
+    lay = S.particle_layers(sc4["position"], sc4["cfg"])
+    with pytest.raises(sphmi.SphError):
+        S.HipSlabBackend(sc4["cfg"], sc4["position"], sc4["velocity"], np.arange(n, dtype=np.uint32),
+                         S.make_slab([int(lay.min()), int(lay.max()) + 1], 0, 1, n))
 
 
 @pytest.mark.gpu
