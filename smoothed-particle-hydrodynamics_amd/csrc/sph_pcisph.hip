@@ -288,8 +288,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
       const float rx = xi.x - xj[k].x, ry = xi.y - xj[k].y, rz = xi.z - xj[k].z;
       const float r2 = (rx * rx + ry * ry + rz * rz) * d.simScale * d.simScale;
       const float a = d.hs2 - r2;
-      const double term = (double)(a * a * a);
-      density = (jj[k] != -1 && r2 < d.hs2) ? density + term : density;
+      // a skipped term is added as +0.0: the sum is >= +0 (it starts there and only grows), so x + 0.0 == x bit for bit
+      const float term = (jj[k] != -1 && r2 < d.hs2) ? a * a * a : 0.f;
+      density += (double)term;
     }
   }
   if (density < (double)d.hs6) density = (double)d.hs6;
