@@ -1,0 +1,21 @@
+"""One-off (not collected by pytest): config #2 at full size, 100 steps on the GPU and on the oracle, every 25 steps all
+positions / velocities / neighbour ids compared bit for bit.   python tests/long_run_parity.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import scenes
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+sc = scenes.liquid_box((50.0, 50.0, 50.0), (100, 100, 100), mask=0xffff)
+N = sc["cfg"].particleCount
+hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=int(os.environ.get("ORACLE_THREADS", "16")))
+t0 = time.time()
+for it in range(steps):
+    hip.step(it); ora.step()
+    if (it + 1) % 25 == 0:
+        ok = (scenes.bits_equal(hip.read_position_buffer(), ora.buffer("position").reshape(-1, 4)[:N])
+              and scenes.bits_equal(hip.read_velocity_buffer(), ora.buffer("velocity").reshape(-1, 4)[:N])
+              and np.array_equal(hip.buffer("neighborIds"), ora.buffer("neighborIds")))
+        print("step %d: %s  (%.0f s)" % (it + 1, "bit-identical" if ok else "MISMATCH", time.time() - t0), flush=True)
+        if not ok:
+            sys.exit(1)
+print("ok")
