@@ -456,9 +456,14 @@ struct StepTail {
 static int enqueue_step(sph_solver* s, const StepTail* tail) {
   int rc;
 #define RUN(stage, call) do { StageTimer t_(s, stage); rc = (call); if (rc != SPH_OK) return rc; } while (0)
-  RUN(SPH_ST_HASH, sphk_hash(s));
-  RUN(SPH_ST_SORT, sphk_sort(s));
-  RUN(SPH_ST_SORT_POST, sphk_sort_post_and_index(s));
+  if (s->hasSlab) {
+    RUN(SPH_ST_SORT, sphk_hash_sort_post_slab(s));
+    RUN(SPH_ST_SORT_POST, sphk_index_fixed(s));
+  } else {
+    RUN(SPH_ST_HASH, sphk_hash(s));
+    RUN(SPH_ST_SORT, sphk_sort(s));
+    RUN(SPH_ST_SORT_POST, sphk_sort_post_and_index(s));
+  }
   // Slab mode: a stage runs only on the ghost layers its results are needed on (owned layers + depth layers per side).
   // Information travels one neighbour hop (<= 31h/30, i.e. 31/60 of a 2h cell layer) per stage, backwards from the owned
   // layers: with `left` predict-correct iterations still to come, the pressure force is needed 2*left hops out and

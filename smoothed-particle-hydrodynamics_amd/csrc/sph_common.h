@@ -136,6 +136,7 @@ int sphk_sort_post(sph_solver* s);        // gather + backIndex (K3)
 int sphk_index_raw(sph_solver* s);        // K4 table with -1 for empty cells
 int sphk_index_fixed(sph_solver* s);      // H2 table (cellStart)
 int sphk_sort_post_and_index(sph_solver* s);  // fused K3 + K4 + H2
+int sphk_hash_sort_post_slab(sph_solver* s);  // slab mode: K2 + sort + K3 with compacted sort keys (2 radix passes)
 // sph_neighbors.hip
 int sphk_clear_neighbors(sph_solver* s);
 int sphk_find_neighbors(sph_solver* s, int ghostDepth = -1);

@@ -15,6 +15,60 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_hash(SphDev d) {
   d.vals[id] = (uint32_t)id;
 }
 
+// Slab mode (fused step): the sort key is the cell id COMPACTED to the cells a slab can hold — the declared grid is sized by h
+// but hashed by 2h, so only ~1/8 of its index space is reachable, and a slab spans few z layers. The
+// mapping (cx, cy, cz) -> cx + usedX*(cy + usedY*(cz - czBase)) is monotone in the real cell id, so the stable sort gives the
+// same order with 2 radix passes instead of 3; k_sort_post_rekey puts the real cell id back into keys[].
+struct CompactKey { int usedX, usedY, czBase, layers; };
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_hash_compact(SphDev d, CompactKey c) {
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 p = d.posOrig[id];
+  const int cx = min(max((int)(p.x * d.cellSizeInv), 0), c.usedX - 1), cy = min(max((int)(p.y * d.cellSizeInv), 0), c.usedY - 1);
+  const int cz = min(max((int)(p.z * d.cellSizeInv) - c.czBase, 0), c.layers - 1);
+  d.keys[id] = (uint32_t)(cx + c.usedX * (cy + c.usedY * cz));
+  d.vals[id] = (uint32_t)id;
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_sort_post_rekey(SphDev d) {
+  const int i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (i >= d.N) return;
+  const uint32_t src = d.vals[i];
+  const float4 p = d.posOrig[src];
+  d.sortedPos[i] = p;
+  d.sortedVel[i] = d.velOrig[src];
+  d.backIndex[src] = (uint32_t)i;
+  const int cx = (int)(p.x * d.cellSizeInv), cy = (int)(p.y * d.cellSizeInv), cz = (int)(p.z * d.cellSizeInv);
+  d.keys[i] = (uint32_t)(cx + cy * d.gx + cz * d.gx * d.gy) & d.cellMask;  // the real cell id, as k_hash computes it
+}
+
+static int bits_for(long long n) { int b = 1; while ((1LL << b) < n) b++; return b; }
+
+// hash + sort + gather of the fused step in slab mode; falls back to the plain path when the compaction does not apply
+int sphk_hash_sort_post_slab(sph_solver* s) {
+  const SphDev& d = s->d;
+  CompactKey c;
+  c.usedX = min((int)(d.xmax * d.cellSizeInv) + 1, d.gx);
+  c.usedY = min((int)(d.ymax * d.cellSizeInv) + 1, d.gy);
+  const long long lo = max((long long)s->slab.layerLo - s->slab.ghostLayers - 2, 0LL);
+  const long long hi = min((long long)s->slab.layerHi + s->slab.ghostLayers + 2, (long long)d.gz);
+  c.czBase = (int)lo; c.layers = (int)max(hi - lo, 1LL);
+  const long long cells = (long long)c.usedX * c.usedY * c.layers;
+  const int bits = bits_for(cells);
+  if (bits >= s->sortBits) {  // nothing to gain
+    int rc = sphk_hash(s);
+    if (rc == SPH_OK) rc = sphk_sort(s);
+    return rc == SPH_OK ? sphk_sort_post(s) : rc;
+  }
+  hipLaunchKernelGGL(k_hash_compact, dim3(sph_blocks(d.N)), dim3(SPH_BLOCK), 0, s->stream, d, c);
+  int rc = sphk_sort_pairs(s, d.N, bits);
+  if (rc != SPH_OK) return rc;
+  hipLaunchKernelGGL(k_sort_post_rekey, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
 int sphk_hash(sph_solver* s) {
   hipLaunchKernelGGL(k_hash, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
   SPH_HIP(hipGetLastError());
