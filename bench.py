@@ -186,6 +186,19 @@ def main():
                 elif workload_name in tr.get("other_workloads", {}):
                     roofline["traffic"] = tr["other_workloads"][workload_name]["hbm_bytes_per_launch"]
 
+    # Multi-GPU sanity after the timed region (outside `value`): the ranks' owned sets must still partition the particles and
+    # every owned particle must be finite — a silent halo failure would show here.
+    partition_ok = None
+    if decomposition is not None:
+        pos_l, vel_l, gid_l, owned_l = solver.slab_read()
+        m = owned_l.astype(bool)
+        stats = torch.tensor([float(m.sum()), float(np.isfinite(pos_l[m]).all() and np.isfinite(vel_l[m]).all()),
+                              float(gid_l[m].astype(np.float64).sum())], dtype=torch.float64,
+                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        partition_ok = bool(int(stats[0].item()) == N and int(stats[1].item()) == world
+                            and abs(stats[2].item() - N * (N - 1) / 2.0) < 0.5)  # every global id exactly once
+
     # SURVEY 8(d) extras, single GPU only and outside `value`: per-step p50 from one event pair per step, and the step
     # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step).
     p50_ms, readback_ms = None, None
@@ -253,7 +266,8 @@ def main():
         if decomposition is not None:
             out["halo"] = {"local_particles_rank0": solver.N, "bytes_sent_rank0_per_step": decomposition.bytes_sent // max(1, it),
                            "exchange_host_ms_per_step_rank0": round(decomposition.exchange_seconds * 1e3 / max(1, it), 4),
-                           "p2p_groups_per_step_rank0": round(decomposition.transfers / max(1, it), 3)}
+                           "p2p_groups_per_step_rank0": round(decomposition.transfers / max(1, it), 3),
+                           "owned_sets_partition_all_particles": partition_ok}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
