@@ -18,7 +18,7 @@
 //      not build the histogram: the cumulative counts it needs are "d^2 < U[j]" tests against 30 thresholds computed
 //      exactly on the host (SphDev::binU), searched by bisection.
 // Particles whose list overflows or whose cells are not fully staged (wrapped / aliased cells, LDS capacity) are queued
-// and served by k_find_neighbors_fallback, the literal two-pass walk over global memory (`find_neighbors_slow`), so the
+// and served by k_find_neighbors_fallback, the literal two-pass walk over global memory (one wave per particle), so the
 // result is exact for any input.
 #include <stdlib.h>
 #include <string.h>
@@ -72,62 +72,6 @@ __device__ __forceinline__ void particle_cells(const SphDev& d, const float4 me,
     cs.cell[k] = c;
     cs.lo[k] = (int)d.cellStart[c];
     cs.hi[k] = (int)d.cellStart[c + 1];
-  }
-}
-
-// Literal restatement of the reference's two passes for one particle, candidates read from global memory.
-// `hist` points at 30 private counters with stride `hstride` (LDS).
-__device__ __forceinline__ void find_neighbors_slow(const SphDev& d, int id, uint32_t* hist, int hstride) {
-  const float4 me = d.sortedPos[id];
-  CellSet cs;
-  particle_cells(d, me, (int)d.keys[id], cs);
-  for (int b = 0; b < SPH_RSEG; b++) hist[b * hstride] = 0u;
-  const float h2 = d.h * d.h;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    for (int j = cs.lo[k]; j < cs.hi[k]; j++) {
-      if (j == id) continue;
-      const float4 o = d.sortedPos[j];
-      const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-      const float d2 = ex * ex + ey * ey + ez * ez;
-      if (d2 <= h2) {
-        const float dist = sqrtf(d2);
-        const int bin = (int)(dist * (float)SPH_RSEG / d.h);
-        if (bin < SPH_RSEG) hist[bin * hstride] += 1u;
-      }
-    }
-  }
-  int jb = 0, sum = 0;  // threshold, sphFluid.cl:310-323
-  while (jb < SPH_RSEG) {
-    sum += (int)hist[jb * hstride];
-    if (sum == SPH_MAXN) break;
-    if (sum > SPH_MAXN) { jb--; break; }
-    jb++;
-  }
-  const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
-  const float r2 = r_thr * r_thr;
-  int found = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (found >= SPH_MAXN) continue;  // `if(spaceLeft>0)`, sphFluid.cl:145
-    for (int j = cs.lo[k]; j < cs.hi[k]; j++) {
-      if (j == id) continue;
-      const float4 o = d.sortedPos[j];
-      const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-      const float d2 = ex * ex + ey * ey + ez * ez;
-      if (d2 <= r2) {
-        if (found >= SPH_MAXN) break;  // sphFluid.cl:169
-        const size_t idx = nbr_index(id, found);
-        d.nbrId[idx] = j;
-        d.nbrDist[idx] = sqrtf(d2) * d.simScale;
-        found++;
-      }
-    }
-  }
-  for (int k = found; k < SPH_MAXN; k++) {
-    const size_t idx = nbr_index(id, k);
-    d.nbrId[idx] = -1;
-    d.nbrDist[idx] = -1.f;
   }
 }
 
@@ -548,7 +492,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
 }
 
 // The queued particles, one WAVE per particle: the 64 lanes take consecutive candidates of a cell, so a particle costs
-// ~2 x 8 x 2 dependent memory round trips instead of ~1300. Same semantics as find_neighbors_slow: pass 0 fills a
+// ~2 x 8 x 2 dependent memory round trips instead of ~1300. The reference's semantics, literally: pass 0 fills a
 // 30-bin histogram (LDS atomics), every lane derives the same r_thr, pass 1 assigns slots in traversal order with a
 // ballot prefix (lane order == candidate order inside a chunk) and stops at 32.
 __global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_fallback(SphDev d, const uint32_t* __restrict__ slowQueue) {
@@ -619,34 +563,16 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_fallback(SphDev d,
   }
 }
 
-// Reference-shaped kernel (one lane per particle, everything from global memory); kept for A/B timing
-// (SPHMI_FIND_NEIGHBORS=v1) and as the semantic baseline of the fast kernel.
-__global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_v1(SphDev d) {
-  __shared__ uint32_t hist[SPH_RSEG][SPH_BLOCK];
-  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
-  find_neighbors_slow(d, id, &hist[0][threadIdx.x], SPH_BLOCK);
-}
-
 int sphk_find_neighbors(sph_solver* s, int ghostDepth) {
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("SPHMI_FIND_NEIGHBORS");
-    variant = (e && !strcmp(e, "v1")) ? 1 : 2;
+  static bool attrSet = false;
+  if (!attrSet) {
+    SPH_HIP(hipFuncSetAttribute((const void*)k_find_neighbors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FnShared)));
+    attrSet = true;
   }
-  if (variant == 1) {
-    hipLaunchKernelGGL(k_find_neighbors_v1, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
-  } else {
-    static bool attrSet = false;
-    if (!attrSet) {
-      SPH_HIP(hipFuncSetAttribute((const void*)k_find_neighbors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FnShared)));
-      attrSet = true;
-    }
-    // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
-    SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
-    hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, sph_ranged(s, ghostDepth), s->d.keysAlt);
-    hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N, 4), 1024)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
-  }
+  // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
+  SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
+  hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, sph_ranged(s, ghostDepth), s->d.keysAlt);
+  hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N, 4), 1024)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
