@@ -4,13 +4,18 @@
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one full simulationStep() (owPhysicsFluidSimulator.cpp:79-149: neighbour search + PCISPH predict-correct
-loop + integration) of BASELINE config #2, the 1M-particle pure-liquid cube of SURVEY §8(d) (N = 1,058,808 including
-the boundary shell, reference-exact 16-bit cell ids), through the C ABI of libsphmi.so with all state resident in HBM.
+loop + integration) of BASELINE config #4, the 16M-particle pure-liquid box of SURVEY §8(d) (N = 16,507,704 including
+the boundary shell, box 78h x 50h x 470h, wide cell ids) — the configuration the metric and both north_star targets are
+quoted on — through the C ABI of libsphmi.so with all state resident in HBM. The same box is used for every --gpus N
+(N > 1: cut into N z-slabs, 4-layer halo exchanged once per step over RCCL), so the series is STRONG scaling.
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
   roofline      the density pass (pcisph_computeDensity): algorithmic bytes = 132 B/particle (32 distances + 1 write,
                 SURVEY §8d) / its mean launch duration, measured with HIP events on the solver's stream inside real steps
+                (2.18 GB per launch: 8x the Infinity Cache, i.e. an HBM figure)
   cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores on the same scene, few steps
   stages_ms     mean device time per stage per step (HIP events), findNeighbors reported as time
+  stages_frac   per stage: algorithmic bytes (lean layout) / time / 8 TB/s
+  config2_1M_cube   the 1M-particle cube of config #2 as an extra block (N = 1 only): value, ms/step, stages
 """
 import argparse
 import json
@@ -36,8 +41,18 @@ WORKLOADS = {
 }
 
 
+DEFAULT_WORKLOAD = "config4_16M_box"
+
+# SURVEY App. D, lean SoA layout: algorithmic bytes per particle of every launch of a stage in one step (pure liquid,
+# 3 predict-correct iterations). sort = 3 radix passes of wide ids x (8 R hist + 8 R + 8 W scatter); find_neighbors 268;
+# density 132; forces ~300 (+32 for the (v, rho) pack); predict_density 3 x 152 (correctPressure fused);
+# pressure_force 2 x (288 + 48 predictPositions) + (288 + 200 integrate).
+STAGE_ALGO_BYTES = {"hash": 20, "sort": 72, "sort_post": 69, "find_neighbors": 268, "density": 132, "forces": 332,
+                    "predict_density": 456, "pressure_force": 1160}
+
+
 def weak_workload(world):
-    """N > 1 default: the config #2 column repeated `world` times along z (1.06M particles per GPU), wide cell ids,
+    """--workload weak: the config #2 column repeated `world` times along z (1.06M particles per GPU), wide cell ids,
     cut into `world` z-slabs with a 4-layer halo exchanged once per step (sphmi/slab.py)."""
     return (50.0, 50.0, 50.0 * world), (100, 100, 100 * world), 0xffffffff
 
@@ -66,9 +81,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2_1M_cube", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-steps", type=int, default=80, help="steps of the CPU baseline, ~10 s on 16 cores (0 = skip)")
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS) + ["weak"],
+                    help="default: config #4 for every --gpus N (strong scaling); 'weak': 1M-particle column per GPU")
+    ap.add_argument("--cpu-steps", type=int, default=-1,
+                    help="steps of the CPU baseline (default: ~10 s of work on 16 cores, e.g. 4 at 16.5 M; 0 = skip)")
     ap.add_argument("--no-stage-pass", action="store_true", help="skip the second, per-stage-timed pass")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config #2 extra block")
     args = ap.parse_args()
 
     import numpy as np
@@ -100,12 +118,14 @@ def main():
         sys.exit("bench.py needs a GPU: libsphmi has no CPU path")
     torch.cuda.set_device(local_rank)
 
-    strong = world > 1 and args.workload != "config2_1M_cube"
-    if world > 1 and not strong:
+    strong = args.workload != "weak"
+    if not strong:
         box, lattice, mask = weak_workload(world)
         workload_name = "weak_%dx_config2_column" % world
     else:
         box, lattice, mask = WORKLOADS[args.workload]
+        if world > 1:
+            mask = 0xffffffff  # the slab decomposition needs wide cell ids
         workload_name = args.workload
     sc = scenes.liquid_box(box, lattice, mask=mask)
     cfg = sc["cfg"]
@@ -160,7 +180,7 @@ def main():
     value = N * args.steps / wall  # N = particles of the whole job (all ranks)
 
     # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
-    stages_ms, roofline = {}, None
+    stages_ms, stages_frac, roofline = {}, {}, None
     if not args.no_stage_pass:
         solver.set_stage_timing(True)
         solver.reset_stage_times()
@@ -178,13 +198,23 @@ def main():
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": None, "avg_launch_us": round(d_ms / d_cnt * 1e3, 2),
                         "bytes_per_launch": n_local * DENSITY_BYTES_PER_PARTICLE}
+            # HBM bytes from the committed rocprofv3 PMC passes of this workload (profiles/README.md) — NOT measured in this
+            # run: counters cannot be read from inside the process
             traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
-            if os.path.exists(traffic_file):  # PMC result of the committed rocprofv3 passes (see profiles/README.md)
+            if os.path.exists(traffic_file) and world == 1:
                 tr = json.load(open(traffic_file))
                 if tr.get("workload") == workload_name:
                     roofline["traffic"] = tr.get("hbm_bytes_per_launch")
                 elif workload_name in tr.get("other_workloads", {}):
                     roofline["traffic"] = tr["other_workloads"][workload_name]["hbm_bytes_per_launch"]
+                if roofline["traffic"] is not None:
+                    roofline["traffic_source"] = "profiles/density_traffic.json (committed rocprofv3 PMC passes; not this run)"
+        # per stage: algorithmic bytes of all its launches in one step / its time / 8 TB/s (pure-liquid scenes)
+        stages_frac = {k: round(n_local * STAGE_ALGO_BYTES[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                       for k, v in stages_ms.items() if k in STAGE_ALGO_BYTES and v > 0}
+        step_ms = sum(stages_ms.values())
+        if step_ms > 0:
+            stages_frac["whole_step_2600B"] = round(n_local * 2600.0 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     # Multi-GPU sanity after the timed region (outside `value`): the ranks' owned sets must still partition the particles and
     # every owned particle must be finite — a silent halo failure would show here.
@@ -223,27 +253,64 @@ def main():
 
     # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
     cpu = None
-    if rank == 0 and args.cpu_steps > 0 and world == 1:
+    cpu_steps = args.cpu_steps
+    if cpu_steps < 0:  # ~10 s on 16 cores at the 6.9e6 particle-steps/s of round 1: 4 steps at 16.5 M, 80 at 1 M
+        cpu_steps = int(max(2, min(80, round(6.9e7 / N))))
+    if rank == 0 and cpu_steps > 0 and world == 1:
         cores = host_cores()
         ora = scenes.oracle_for(sc, threads=cores)
         ora.step()  # warm-up (page faults, first-touch)
         c0 = time.perf_counter()
-        for _ in range(args.cpu_steps):
+        for _ in range(cpu_steps):
             ora.step()
         cw = time.perf_counter() - c0
-        cpu = {"value": round(N * args.cpu_steps / cw, 1), "unit": "particle-steps/s", "cores": cores, "kind": "port",
-               "sample": "%d steps of the same %d-particle scene after 1 warm-up step (oracle/sph_oracle.c, OpenMP)"
-                         % (args.cpu_steps, N), "ms_per_step": round(cw * 1e3 / args.cpu_steps, 2)}
+        cpu = {"value": round(N * cpu_steps / cw, 1), "unit": "particle-steps/s", "cores": cores, "kind": "port",
+               "sample": "%d steps of the same %d-particle scene after 1 warm-up step (oracle/sph_oracle.c, OpenMP, %d threads)"
+                         % (cpu_steps, N, cores), "ms_per_step": round(cw * 1e3 / cpu_steps, 2)}
         ora.close()
-        one = scenes.oracle_for(sc, threads=1)  # the 1-thread figure SURVEY 8(d) asks for beside the all-cores one
+        del ora
+        # the 1-thread figure SURVEY 8(d) asks for beside the all-cores one, on the <= 1 M-particle cube of config #2
+        # (a 1-thread step of the 16.5 M box takes ~26 s)
+        sc1 = sc if N <= 1100000 else scenes.liquid_box(*WORKLOADS["config2_1M_cube"][:2], mask=WORKLOADS["config2_1M_cube"][2])
+        one = scenes.oracle_for(sc1, threads=1)
         one.step()
         c0 = time.perf_counter()
-        n1 = max(1, min(2, args.cpu_steps))
+        n1 = 2
         for _ in range(n1):
             one.step()
         c1 = time.perf_counter() - c0
         one.close()
-        cpu["single_thread_value"] = round(N * n1 / c1, 1)
+        cpu["single_thread_value"] = round(sc1["cfg"].particleCount * n1 / c1, 1)
+        cpu["single_thread_sample"] = "%d steps of the %d-particle cube of config #2, 1 thread" % (n1, sc1["cfg"].particleCount)
+
+    # extra block: BASELINE config #2 (1M cube, reference-exact 16-bit cell ids), GPU only, outside `value`
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and workload_name != "config2_1M_cube":
+        solver.close()
+        b2, l2, m2 = WORKLOADS["config2_1M_cube"]
+        sc2 = scenes.liquid_box(b2, l2, mask=m2)
+        sc2["cfg"].device = local_rank
+        sc2["cfg"].stream = stream.cuda_stream
+        s2 = sphmi.owHIPSolver(sc2["cfg"], sc2["position"], sc2["velocity"])
+        n2 = sc2["cfg"].particleCount
+        for i in range(5):
+            s2.step(i)
+        torch.cuda.synchronize()
+        k = 50
+        e0 = time.perf_counter()
+        for i in range(k):
+            s2.step(5 + i)
+        torch.cuda.synchronize()
+        w2 = time.perf_counter() - e0
+        s2.set_stage_timing(True)
+        s2.reset_stage_times()
+        for i in range(20):
+            s2.step(55 + i)
+        st2 = s2.stage_times()
+        s2.set_stage_timing(False)
+        extra = {"particles": n2, "cell_ids": "ref16", "steps": k, "ms_per_step": round(w2 * 1e3 / k, 4),
+                 "value": round(n2 * k / w2, 1), "stages_ms": {a: round(ms / 20, 5) for a, (ms, cnt) in st2.items() if cnt}}
+        s2.close()
 
     if rank == 0:
         out = {
@@ -259,8 +326,10 @@ def main():
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "ms_per_step_p50": None if p50_ms is None else round(p50_ms, 4),
             "ms_per_step_with_position_readback": None if readback_ms is None else round(readback_ms, 4),
-            "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms,
+            "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms, "stages_frac": stages_frac,
         }
+        if extra:
+            out["config2_1M_cube"] = extra
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if decomposition is not None:

@@ -156,6 +156,25 @@ extern "C" int sph_get_stage_times(sph_solver* s, double* ms_total, int64_t* lau
 }
 
 // ---------------------------------------------------------------------------------------------- create / destroy
+// Two different libamdhip64 files in one process (e.g. /opt/rocm's and the copy bundled with PyTorch) do not both see the
+// GPU. Returns true and the two paths if /proc/self/maps shows that situation.
+static bool two_hip_runtimes(char* out, size_t cap) {
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) return false;
+  char line[1024], first[512] = "";
+  bool two = false;
+  while (!two && fgets(line, sizeof(line), f)) {
+    if (!strstr(line, "libamdhip64")) continue;
+    char* path = strchr(line, '/');
+    if (!path) continue;
+    path[strcspn(path, "\n")] = 0;
+    if (!first[0]) snprintf(first, sizeof(first), "%s", path);
+    else if (strcmp(first, path) != 0) { snprintf(out, cap, "%s and %s", first, path); two = true; }
+  }
+  fclose(f);
+  return two;
+}
+
 static void free_all(sph_solver* s) {
   SphDev& d = s->d;
   void* ptrs[] = {d.elasticMask, d.velRho, d.bndMask, d.posPress, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
@@ -204,8 +223,17 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   if (!(cfg->h > 0.f) || !(cfg->hashGridCellSize > 0.f)) { sph_set_error("h / hashGridCellSize must be positive"); return SPH_ERR_INVALID; }
 
   int ndev = 0;
-  SPH_HIP(hipGetDeviceCount(&ndev));
-  if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { sph_set_error("no HIP device %d (found %d): libsphmi has no CPU fallback", cfg->device, ndev); return SPH_ERR_HIP; }
+  const hipError_t devErr = hipGetDeviceCount(&ndev);
+  if (devErr != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    char two[300];
+    if (two_hip_runtimes(two, sizeof(two)))  // the usual cause of "no ROCm-capable device" on a box that has one
+      sph_set_error("no HIP device %d (found %d): two HIP runtimes are mapped into this process (%s); load the one the rest of the "
+                    "process uses BEFORE libsphmi.so so that both bind to it", cfg->device, ndev, two);
+    else
+      sph_set_error("no HIP device %d (found %d%s%s): libsphmi has no CPU fallback", cfg->device, ndev,
+                    devErr != hipSuccess ? ", " : "", devErr != hipSuccess ? hipGetErrorString(devErr) : "");
+    return SPH_ERR_HIP;
+  }
   SPH_HIP(hipSetDevice(cfg->device));
 
   sph_solver* s = new sph_solver();

@@ -99,18 +99,43 @@ HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_
                          "sphmi_trajectory_membranes"]
 
 
+def hip_runtimes_loaded():
+    """Paths of every libamdhip64 mapped into this process (two of them do not both see the GPU)."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def _bind_one_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's). Whichever copy is mapped first serves every
+    later user, so if none is loaded yet and torch is installed, map torch's copy now — by path, without importing torch —
+    and libsphmi.so, a later `import torch` and RCCL all share it, whatever the import order."""
+    if hip_runtimes_loaded():
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def device_lib():
     """Load libsphmi.so (the HIP solver). Raises if it has not been built — there is no fallback."""
     global _dev
     if _dev is None:
         if not os.path.exists(LIB_PATH):
             raise SphError("libsphmi.so not built: the HIP extension is required (no CPU fallback exists)")
-        # PyTorch-ROCm ships its own copy of libamdhip64. If it is going to live in this process it must be loaded first,
-        # so that libsphmi.so binds to that same runtime; two HIP runtimes in one process do not both see the GPU.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        _bind_one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.sph_create.argtypes = [C.POINTER(SphConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_void_p)]

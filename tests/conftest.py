@@ -2,7 +2,6 @@ import os
 import sys
 
 import pytest
-import torch  # noqa: F401  -- before anything dlopens libsphmi.so: see sphmi.device_lib()
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd")):
