@@ -94,6 +94,20 @@ static void compute_bin_thresholds(float h, float* U) {
     U[j] = bits_to_float(lo < h2next ? lo : h2next);
   }
   U[SPH_RSEG] = U[SPH_RSEG + 1] = bits_to_float(h2next);
+  // U[32 + jb], jb = 0..30: r_thr^2 of pass 1, r_thr = (float)(jb + 1) * h / (float)radius_segments evaluated in float like
+  // sphFluid.cl:313-321 (jb = 30: "fewer than 32 candidates", r_thr = 31h/30)
+  for (int jb = 0; jb <= SPH_RSEG; jb++) {
+    volatile float a = (float)(jb + 1) * h;
+    volatile float r = a / (float)SPH_RSEG;
+    volatile float r2 = r * r;
+    U[32 + jb] = r2;
+  }
+  // U[63]: radius^2 of the search kernel's filter, a superset of pass 0 (h) and of every pass-1 radius (<= 31h/30)
+  {
+    const float rmax2 = U[32 + SPH_RSEG] > h2 ? U[32 + SPH_RSEG] : h2;
+    volatile float f = rmax2 * (1.f + 0x1p-20f);
+    U[63] = f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- timing
@@ -139,7 +153,7 @@ extern "C" int sph_set_stage_timing(sph_solver* s, int enable) {
 extern "C" int sph_reset_stage_times(sph_solver* s) {
   if (!s) return SPH_ERR_INVALID;
   int rc = resolve_pending(s);
-  hipMemsetAsync(s->d.dbg, 0, sizeof(uint32_t) * 16, s->stream);
+  hipMemsetAsync(s->d.dbg, 0, sizeof(uint32_t) * SPH_DBG_WORDS, s->stream);
   memset(s->stageMs, 0, sizeof(s->stageMs));
   memset(s->stageLaunches, 0, sizeof(s->stageLaunches));
   return rc;
@@ -295,9 +309,9 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
   A(s->blockHist, (size_t)256 * s->maxSortBlocks + 256);  // [256][maxSortBlocks] block histograms + 256 digit totals
   A(d.gid, n); A(d.owned, n); A(s->slabCounts, 12);
-  A(d.dbg, 16);
+  A(d.dbg, SPH_DBG_WORDS);
   float* binU = nullptr;
-  A(binU, 32);
+  A(binU, 64);
   d.binU = binU;
   if (d.hasElastic) {
     A(d.elasticMask, n); A(d.membDelta, n); A(d.elastic, (size_t)32 * d.numElastic); A(d.muscle, (size_t)d.muscleCount);
@@ -321,7 +335,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
     }
   }
   {
-    float U[32];
+    float U[64];
     compute_bin_thresholds(cfg->h, U);
     UP(binU, U, sizeof(U));
   }
@@ -335,7 +349,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   hipMemsetAsync(d.pressure, 0, sizeof(float) * n, s->stream);
   hipMemsetAsync(d.nbrId, 0xff, sizeof(int32_t) * mapN, s->stream);
   hipMemsetAsync(d.nbrDist, 0, sizeof(float) * mapN, s->stream);
-  hipMemsetAsync(d.dbg, 0, sizeof(uint32_t) * 16, s->stream);
+  hipMemsetAsync(d.dbg, 0, sizeof(uint32_t) * SPH_DBG_WORDS, s->stream);
   hipMemsetAsync(d.cellStartRaw, 0, sizeof(uint32_t) * G1, s->stream);
   hipMemsetAsync(d.cellStart, 0, sizeof(uint32_t) * G1, s->stream);
   hipMemsetAsync(d.sortedPos, 0, sizeof(float4) * n, s->stream);
@@ -616,7 +630,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   else if (!strcmp(name, "gridCellIndexFixedUp")) { which = B_GCIF; need = sizeof(uint32_t) * G1; }
   else if (!strcmp(name, "pressure")) { which = B_P; need = sizeof(float) * n; }
   else if (!strcmp(name, "rho")) { which = B_RHO; need = sizeof(float) * 2 * n; }
-  else if (!strcmp(name, "debugCounters")) { which = B_DBG; need = sizeof(uint32_t) * 16; }
+  else if (!strcmp(name, "debugCounters")) { which = B_DBG; need = sizeof(uint32_t) * SPH_DBG_WORDS; }
   else { sph_set_error("unknown buffer '%s'", name); return SPH_ERR_UNKNOWN_BUFFER; }
   if (needed) *needed = need;
   if (!out) return SPH_OK;
@@ -675,7 +689,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
     case B_GCI: rc = d2h(s, o, d.cellStartRaw, sizeof(uint32_t) * G1); break;
     case B_GCIF: rc = d2h(s, o, d.cellStart, sizeof(uint32_t) * G1); break;
     case B_P: rc = d2h(s, o, d.pressure, sizeof(float) * n); break;
-    case B_DBG: rc = d2h(s, o, d.dbg, sizeof(uint32_t) * 16); break;
+    case B_DBG: rc = d2h(s, o, d.dbg, sizeof(uint32_t) * SPH_DBG_WORDS); break;
     case B_RHO:
       rc = d2h(s, o, d.rho, sizeof(float) * n);
       if (rc == SPH_OK) rc = d2h(s, o + sizeof(float) * n, d.rhoPred, sizeof(float) * n);

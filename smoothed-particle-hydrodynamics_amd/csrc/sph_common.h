@@ -21,6 +21,7 @@
 #define SPH_TILE 64
 #define SPH_MAXN 32
 #define SPH_RSEG 30  // radius_segments, sphFluid.cl:116
+#define SPH_DBG_WORDS 32  // diagnostic counters (SphDev::dbg)
 
 struct SphDev {  // what the kernels see; passed by value
   int N, G;
@@ -60,8 +61,9 @@ struct SphDev {  // what the kernels see; passed by value
   float4* elastic;
   int32_t *membraneData, *pml;
   float* muscle;
-  const float* binU;  // 32 floats: d^2 < binU[j] <=> the candidate is counted in radial-histogram bins 0..j (sph_api.hip)
-  uint32_t* dbg;  // 16 diagnostic counters (neighbour-search fallbacks etc.), zeroed by sph_reset_stage_times
+  const float* binU;  // 64 floats: [0..31] d^2 < binU[j] <=> the candidate is counted in radial-histogram bins 0..j;
+                      // [32..62] pass-1 radii r_thr(jb)^2; [63] the search kernel's filter radius^2 (sph_api.hip)
+  uint32_t* dbg;  // SPH_DBG_WORDS diagnostic counters (neighbour-search fallbacks etc.), zeroed by sph_reset_stage_times
 };
 
 struct sph_solver {

@@ -5,23 +5,30 @@
 // histogram of candidates with d^2 <= h^2, from which r_thr is chosen so that at most 32 remain (or 31h/30 if fewer
 // than 32 exist); pass 1 appends candidates with d^2 <= r_thr^2 in traversal order, at most 32.
 //
-// MI355X design: the reference walks ~640 candidates twice per particle and does the expensive part
+// MI355X design. The reference walks ~640 candidates twice per particle and does the expensive part
 // (sqrt, IEEE divide, histogram / store) under a branch that ~7 % of the lanes take but ~99 % of the waves execute.
-// Here a 256-thread workgroup owns 128 consecutive sorted particles (two lanes per particle), stages the <= 9
+// Here a 512-thread workgroup owns 128 consecutive sorted particles, FOUR lanes per particle (a DPP quad), stages the <= 9
 // contiguous runs of sorted particles that can contain their candidates (cells are contiguous along x in the sorted
 // order) into LDS once as SoA x/y/z, and each lane
-//   1. walks 4 of the particle's 8 cells ONCE, four candidates per trip (16-byte aligned LDS reads, packed-f32 math,
-//      next quad prefetched), with the cheap filter d^2 <= max(h, 31h/30)^2 — a superset of both reference passes — and
-//      appends the LDS slot of every hit to a private u16 list in LDS (compaction: ~45 of ~640 candidates survive),
-//   2. replays pass 0 / threshold / pass 1 of the reference over that short list in registers, in traversal order,
-//      with exactly the reference's float expressions, so r_thr, slot order and distances are bit-identical. Pass 0 does
-//      not build the histogram: the cumulative counts it needs are "d^2 < U[j]" tests against 30 thresholds computed
-//      exactly on the host (SphDev::binU), searched by bisection.
-// Particles whose list overflows or whose cells are not fully staged (wrapped / aliased cells, LDS capacity) are queued
-// and served by k_find_neighbors_fallback, the literal two-pass walk over global memory (one wave per particle), so the
-// result is exact for any input.
+//   1. walks one HALF of four of the particle's 8 cells ONCE (~160 candidates), four candidates per trip (16-byte aligned
+//      LDS reads, packed-f32 math, next quad prefetched), with the cheap filter d^2 <= max(h, 31h/30)^2 — a superset of both
+//      reference passes — and appends the LDS slot of every hit to a private u16 list in LDS (~12 of ~160 survive),
+//   2. replays pass 0 / threshold / pass 1 of the reference over that short list in registers (24 entries), in traversal
+//      order, with exactly the reference's float expressions, so r_thr, slot order and distances are bit-identical. Pass 0
+//      does not build the histogram: the cumulative counts it needs are "d^2 < U[j]" tests against 30 thresholds computed
+//      exactly on the host (binU), searched by bisection; counts are combined inside the quad with DPP adds.
+// Why quads: the round-1 kernel (two lanes per particle, 48-entry register arrays) needed 247 VGPRs and 74 KB of LDS per
+// 4 waves — 2 waves per SIMD — and its waves spent 44 % of their cycles waiting with nobody to cover for them (rocprofv3 SQ
+// counters, profiles/r02). Four lanes per particle halve both the list length and the per-wave LDS: <= 128 VGPRs and
+// 75 KB per 8 waves, i.e. 4 waves per SIMD.
+// Particles whose list overflows or whose cells are not fully staged (wrapped / aliased cells, LDS capacity) are served at
+// the end of the batch by the literal two-pass walk, one WAVE per particle, reading the staged candidates from LDS where
+// they are staged and from global memory otherwise — so the result is exact for any input and no second kernel or queue
+// is needed.
 #include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "sph_common.h"
 
@@ -41,51 +48,35 @@ int sphk_clear_neighbors(sph_solver* s) {
   return SPH_OK;
 }
 
+// What the search kernel needs of SphDev (a by-value SphDev costs ~100 SGPRs, half of them spilled).
+struct FnParams {
+  int G, gx, gy, rangeLo, rangeHi;
+  float h, cellSize, cellSizeInv, simScale, xmin, ymin, zmin;
+  const float4* sortedPos;
+  const uint32_t *keys, *cellStart;
+  int32_t* nbrId;
+  float* nbrDist;
+  const float* binU;  // [0..31] pass-0 thresholds U[j]; [32..62] pass-1 radii r_thr(jb)^2, jb = 0..30; [63] the filter radius^2
+  uint32_t* dbg;
+};
+
 __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFluid.cl:94-112
   if (c < 0) c += G;
   if (c >= G) c -= G;
   return c;
 }
 
-// The 8 cells of a particle in the reference's traversal order, as sorted-index ranges [lo, hi).
-struct CellSet { int lo[8], hi[8], row[8], cell[8]; };
-
-__device__ __forceinline__ void particle_cells(const SphDev& d, const float4 me, int myCell, CellSet& cs) {
-  // which neighbour in x/y/z: -1 if the particle sits in the low half of its cell (sphFluid.cl:253-271)
-  const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
-  const float cfx = (float)(int)(me.x * d.cellSizeInv) * d.cellSize;
-  const float cfy = (float)(int)(me.y * d.cellSizeInv) * d.cellSize;
-  const float cfz = (float)(int)(me.z * d.cellSizeInv) * d.cellSize;
-  const int dx = ((px - cfx) < d.h) ? -1 : 1;
-  const int dy = ((py - cfy) < d.h) ? -1 : 1;
-  const int dz = ((pz - cfz) < d.h) ? -1 : 1;
-  const int sy = dy * d.gx, sz = dz * d.gx * d.gy;
-  const int off[8] = {0, dx, sy, sz, dx + sy, dx + sz, sy + sz, dx + sy + sz};
-  const int ry = dy + 1, rz = dz + 1;  // staged-row ids: row = (y step + 1) + 3 * (z step + 1)
-  const int rows[8] = {4, 4, ry + 3, 1 + 3 * rz, ry + 3, 1 + 3 * rz, ry + 3 * rz, ry + 3 * rz};
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int raw = myCell + off[k];
-    int c = wrap_cell(raw, d.G);
-    cs.row[k] = (c == raw) ? rows[k] : -1;  // wrapped cells are never staged
-    c = min(max(c, 0), d.G - 1);            // no-op for particles inside the box; keeps the table read in range
-    cs.cell[k] = c;
-    cs.lo[k] = (int)d.cellStart[c];
-    cs.hi[k] = (int)d.cellStart[c + 1];
-  }
-}
-
-#ifndef FN_PART
-#define FN_PART 128         // particles per workgroup (A/B on config #2: 128 -> 0.89 ms, 256 -> 0.96 ms)
-#endif
-#define FN_THREADS (2 * FN_PART)  // two lanes per particle
+#define FN_PART 128               // particles per workgroup
+#define FN_LANES 4                // lanes per particle (one DPP quad)
+#define FN_THREADS (FN_LANES * FN_PART)
+#define FN_WAVES (FN_THREADS / 64)
 #ifndef FN_CAND_CAP
-#define FN_CAND_CAP 4096    // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
+#define FN_CAND_CAP 4096          // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
 #endif
-#define FN_WIN 16           // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
-#define FN_CAND_PAD 12      // the aligned, prefetching 4-wide walk reads (never uses) up to 11 slots past a cell
+#define FN_WIN 16                 // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
+#define FN_CAND_PAD 12            // the aligned, prefetching 4-wide walk reads (never uses) up to 11 slots past a piece
 #ifndef FN_LIST_CAP
-#define FN_LIST_CAP 48      // compaction list entries per lane (u16 [entry][lane])
+#define FN_LIST_CAP 24            // compaction list entries per lane (u16 [entry][lane]); 96 per particle
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -94,30 +85,154 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct FnShared {
   float x[FN_CAND_CAP + FN_CAND_PAD], y[FN_CAND_CAP + FN_CAND_PAD], z[FN_CAND_CAP + FN_CAND_PAD];  // staged candidates
   uint16_t list[FN_LIST_CAP][FN_THREADS];         // [entry][lane] LDS slots of the filter hits, traversal order
-  float binU[32];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j (see SphDev::binU)
+  float binU[64];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j; r_thr^2 table; filter radius (see SphDev::binU)
   int rowLo[9], rowHi[9], rowBase[9];             // staged runs: sorted-index range and first LDS slot
   int win[9][FN_WIN];                             // cellStart[] of the cells cLo-1 .. of every row (see the staging code)
   int segEnd[9], segDelta[9];                     // flat staging: LDS slots < segEnd[q] belong to run q; sorted index = slot + segDelta[q]
   int total, winOk;                               // staged candidates; 1 if the window covers the batch's cells
   int batchLo, batchHi, retry;                    // current batch of particles; retry: small-batch mode
+  int nSlow;                                      // particles of this batch left to the exact wave-per-particle walk
+  int slowList[FN_PART];
+  uint32_t hist[FN_WAVES][32];                    // radial histograms of the wave-per-particle walk
+#ifdef FN_STAMPS
+  uint32_t stamps[16];                            // diagnostic build: cycles per phase, summed over the workgroup's waves
+#endif
 };
 
-// d.dbg layout: [0] particles handed to the fallback kernel because a cell was not staged, [1] because a list
-// overflowed, [3] candidate runs dropped for LDS capacity, [4] fallback queue length.
-//
-// Lane pair (2p, 2p+1) serves particle p: lane 0 walks the cells k = 0,5,6,7 of the reference's order and lane 1 the
-// cells 1,2,3,4, so the merged traversal order is A0 B1 B2 B3 B4 A5 A6 A7 and only four per-cell hit counts have to
-// cross lanes (one DPP swap each) to place every neighbour in the reference's slot.
-__global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint32_t* __restrict__ slowQueue) {
+// DPP moves inside a quad (4 consecutive lanes = the lanes of one particle): value of lane (l ^ 1), (l ^ 2)
+__device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }  // quad_perm [2,3,0,1]
+
+// d.dbg layout: [0] particles handed to the exact wave-per-particle walk because a cell was not staged, [1] because a list
+// overflowed, [3] candidate runs dropped for LDS capacity. With FN_STAMPS (diagnostic build only): [16..25] cycles / 64 per phase.
+#ifdef FN_STAMPS
+#define FN_STAMP(ph)                                                                                      \
+  {                                                                                                       \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh.stamps[(ph)], (uint32_t)(t_ - stamp_));                    \
+    stamp_ = __builtin_amdgcn_s_memtime();                                                                \
+  }
+#else
+#define FN_STAMP(ph)
+#endif
+
+// The literal reference walk for ONE particle by one wave (the 64 lanes take consecutive candidates of a cell): pass 0 fills a
+// 30-bin histogram (LDS atomics), every lane derives the same r_thr, pass 1 assigns slots in traversal order with a ballot
+// prefix (lane order == candidate order inside a chunk) and stops at 32. Candidates come from the staged LDS copy where the
+// cell is staged (the usual case: a list overflowed) and from global memory otherwise (wrapped / aliased / dropped cells).
+__device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, int id, int wave, int lane) {
+  const float4 me = d.sortedPos[id];
+  const int myCell = (int)d.keys[id];
+  int lo[8], hi[8], ldsBase[8];  // sorted-index range of each cell; first LDS slot or -1 if the cell is not staged
+  {
+    const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
+    const float cfx = (float)(int)(me.x * d.cellSizeInv) * d.cellSize;
+    const float cfy = (float)(int)(me.y * d.cellSizeInv) * d.cellSize;
+    const float cfz = (float)(int)(me.z * d.cellSizeInv) * d.cellSize;
+    const int dx = ((px - cfx) < d.h) ? -1 : 1;
+    const int dy = ((py - cfy) < d.h) ? -1 : 1;
+    const int dz = ((pz - cfz) < d.h) ? -1 : 1;
+    const int sy = dy * d.gx, sz = dz * d.gx * d.gy;
+    const int off[8] = {0, dx, sy, sz, dx + sy, dx + sz, sy + sz, dx + sy + sz};
+    const int ry = dy + 1, rz = dz + 1;  // staged-row ids: row = (y step + 1) + 3 * (z step + 1)
+    const int rows[8] = {4, 4, ry + 3, 1 + 3 * rz, ry + 3, 1 + 3 * rz, ry + 3 * rz, ry + 3 * rz};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int raw = myCell + off[k];
+      int c = wrap_cell(raw, d.G);
+      const int r = (c == raw) ? rows[k] : -1;  // wrapped cells are never staged
+      c = min(max(c, 0), d.G - 1);              // no-op for particles inside the box; keeps the table read in range
+      lo[k] = (int)d.cellStart[c];
+      hi[k] = (int)d.cellStart[c + 1];
+      ldsBase[k] = -1;
+#ifndef FN_EXACT_GLOBAL
+      if (r >= 0 && hi[k] > lo[k] && lo[k] >= sh.rowLo[r] && hi[k] <= sh.rowHi[r]) ldsBase[k] = sh.rowBase[r] + (lo[k] - sh.rowLo[r]);
+#endif
+    }
+  }
+  if (lane < 32) sh.hist[wave][lane] = 0u;
+  const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const float h2 = d.h * d.h;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    for (int j0 = lo[k]; j0 < hi[k]; j0 += 64) {
+      const int j = j0 + lane;
+      if (j < hi[k] && j != id) {
+        float ox, oy, oz;
+        if (ldsBase[k] >= 0) { const int sl = ldsBase[k] + (j - lo[k]); ox = sh.x[sl]; oy = sh.y[sl]; oz = sh.z[sl]; }
+        else { const float4 o = d.sortedPos[j]; ox = o.x; oy = o.y; oz = o.z; }
+        const float ex = me.x - ox, ey = me.y - oy, ez = me.z - oz;
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        if (d2 <= h2) {
+          const float dist = sqrtf(d2);
+          const int bin = (int)(dist * (float)SPH_RSEG / d.h);
+          if (bin < SPH_RSEG) atomicAdd(&sh.hist[wave][bin], 1u);
+        }
+      }
+    }
+  }
+  int jb = 0, sum = 0;  // threshold, sphFluid.cl:310-323 (LDS ops of one wave retire in order: the adds are visible)
+  while (jb < SPH_RSEG) {
+    sum += (int)sh.hist[wave][jb];
+    if (sum == SPH_MAXN) break;
+    if (sum > SPH_MAXN) { jb--; break; }
+    jb++;
+  }
+  const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
+  const float r2 = r_thr * r_thr;
+  int found = 0;  // wave-uniform
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    for (int j0 = lo[k]; j0 < hi[k] && found < SPH_MAXN; j0 += 64) {
+      const int j = j0 + lane;
+      float d2 = 0.f;
+      bool hit = false;
+      if (j < hi[k] && j != id) {
+        float ox, oy, oz;
+        if (ldsBase[k] >= 0) { const int sl = ldsBase[k] + (j - lo[k]); ox = sh.x[sl]; oy = sh.y[sl]; oz = sh.z[sl]; }
+        else { const float4 o = d.sortedPos[j]; ox = o.x; oy = o.y; oz = o.z; }
+        const float ex = me.x - ox, ey = me.y - oy, ez = me.z - oz;
+        d2 = ex * ex + ey * ey + ez * ez;
+        hit = d2 <= r2;
+      }
+      const unsigned long long m = __ballot(hit);
+      const int pos = found + __popcll(m & ltMask);
+      if (hit && pos < SPH_MAXN) {
+        const size_t idx = nbr_index(id, pos);
+        d.nbrId[idx] = j;
+        d.nbrDist[idx] = sqrtf(d2) * d.simScale;
+      }
+      found += __popcll(m);
+    }
+  }
+  if (lane >= min(found, SPH_MAXN) && lane < SPH_MAXN) {
+    const size_t idx = nbr_index(id, lane);
+    d.nbrId[idx] = -1;
+    d.nbrDist[idx] = -1.f;
+  }
+}
+
+// Quad (4p .. 4p+3) serves particle p. Lanes 0,1 (pair A) walk the cells k = 0,5,6,7 of the reference's order and lanes 2,3
+// (pair B) the cells 1,2,3,4; inside a pair, lane `sub` = 0 takes the first half of every cell (in sorted-index order) and
+// lane 1 the second half. The merged traversal order is therefore
+//   A0.0 A0.1 | B1.0 B1.1 B2.0 B2.1 B3.0 B3.1 B4.0 B4.1 | A5.0 A5.1 A6.0 A6.1 A7.0 A7.1
+// and four per-piece hit counts per lane (one packed word, two DPP moves) place every neighbour in the reference's slot.
+// Pair A gets 54 % of the hits (own cell ~42 %, edges 5 % each, corner 2 %), pair B 46 % (faces ~14 % each, one edge).
+__global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
   const int tid = threadIdx.x;
-  const int p = tid >> 1, half = tid & 1;
+  const int p = tid >> 2, quadLane = tid & 3, pairB = quadLane >> 1, sub = quadLane & 1;
   const int rangeBegin = (int)d.cellStart[d.rangeLo], rangeEnd = (int)d.cellStart[d.rangeHi];  // all particles, or fewer ghost layers
   const int p0 = rangeBegin + blockIdx.x * FN_PART;
   if (p0 >= rangeEnd) return;  // uniform
   const int id = p0 + p;
   const bool alive = id < rangeEnd;
+#ifdef FN_STAMPS
+  if (tid < 16) sh.stamps[tid] = 0u;
+  __syncthreads();
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- stage the candidate runs. Cells of a batch of particles lie in [cLo, cHi]; row r = (sy+1) + 3*(sz+1) holds the
   // cells [cLo - 1, cHi + 1] shifted by sy*gx + sz*gx*gy, which is one contiguous run of sorted particles. Normally the
@@ -130,7 +245,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   const int myCell = alive ? (int)d.keys[id] : 0;
   if (tid == 0) { sh.batchLo = p0; sh.retry = 0; }
   while (true) {
-  __syncthreads();  // (also protects the LDS of the previous batch)
+  __syncthreads();  // (also protects the LDS of the previous batch, including its exact walks)
   const int batchLo = sh.batchLo;
   if (batchLo >= blockHi) break;  // uniform
   if (tid < 64) {
@@ -141,13 +256,14 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
       const bool stop = (tid >= 32) || (i >= blockHi) || (d.keys[min(i, blockHi - 1)] / (unsigned)d.gx != row0);
       len = __ffsll((long long)__ballot(stop)) - 1;  // first lane that must not join the batch (lane 32 at the latest)
     }
-    if (tid == 0) sh.batchHi = batchLo + len;
+    if (tid == 0) { sh.batchHi = batchLo + len; sh.nSlow = 0; }
   }
   __syncthreads();
+  FN_STAMP(0)
   const int batchHi = sh.batchHi;
-  // Every global round trip below is on the workgroup's critical path (two workgroups per CU cannot hide them), so the
-  // staging is three trips deep: (1) the batch's first / last cell, (2) the cell table of the 9 rows into LDS, (3) all
-  // candidate records at once, flat over the concatenated runs.
+  // Every global round trip below is on the workgroup's critical path, so the staging is three trips deep: (1) the batch's
+  // first / last cell, (2) the cell table of the 9 rows into LDS, (3) all candidate records at once, flat over the
+  // concatenated runs. The other workgroup of the CU covers for it meanwhile.
   const int cLo = (int)d.keys[batchLo], cHi = (int)d.keys[batchHi - 1];
   const int nc = cHi - cLo + 3;  // cells per row: cLo-1 .. cHi+1; the window holds nc+1 table entries
   const bool winOk = nc + 1 <= FN_WIN;
@@ -157,39 +273,60 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     const int shift = sy * d.gx + sz * d.gx * d.gy;
     if (winOk) {
       if (i <= nc) sh.win[r][i] = (int)d.cellStart[min(max(cLo - 1 + shift + i, 0), d.G)];
-    } else if (i < 2) {  // sparse cells: only the two ends of the run (particle_cells reads the table directly)
+    } else if (i < 2) {  // sparse cells: only the two ends of the run (the per-particle setup reads the table directly)
       const int a = max(cLo - 1 + shift, 0), b = min(cHi + 1 + shift, d.G - 1);
       sh.win[r][i] = (a <= b) ? (int)d.cellStart[i == 0 ? a : b + 1] : 0;
     }
   }
-  if (tid >= 192 && tid < 224) sh.binU[tid - 192] = d.binU[tid - 192];
+  if (tid >= 192 && tid < 256) sh.binU[tid - 192] = d.binU[tid - 192];
   __syncthreads();
-  if (tid == 0) {
-    int total = 0;
-    for (int r = 0; r < 9; r++) {
-      const int lo = sh.win[r][0], hi = winOk ? sh.win[r][nc] : sh.win[r][1];
-      sh.rowLo[r] = lo; sh.rowHi[r] = max(hi, lo);  // (clamped table reads: an out-of-grid run is empty)
-      total += sh.rowHi[r] - lo;
+  FN_STAMP(1)
+  if (tid < 64) {
+    // run table by the first 9 lanes: the own row (4) first, then the others — if LDS still runs out, the most-used runs
+    // are the ones that are staged. Lane q handles run order[q]; its base is the sum of the earlier runs' lengths.
+    const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+    int r = 0, lo = 0, n = 0;
+    if (tid < 9) {
+      r = order[tid];
+      lo = sh.win[r][0];
+      const int hi = winOk ? sh.win[r][nc] : sh.win[r][1];
+      n = max(hi, lo) - lo;  // (clamped table reads: an out-of-grid run is empty)
     }
-    sh.winOk = winOk ? 1 : 0;
-    if (total > FN_CAND_CAP && !sh.retry) sh.retry = 2;  // 2 = "switch now": redo this workgroup in small batches
-    else {
+    int incl = n;  // inclusive prefix sum over lanes 0..8 (DPP row shifts; lanes >= 9 hold 0)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+    const int total = __shfl(incl, 8);
+    const bool tooBig = total > FN_CAND_CAP;
+    if (tooBig && !sh.retry) {
+      if (tid == 0) sh.retry = 2;  // 2 = "switch now": redo this workgroup in small batches
+    } else if (!tooBig) {
+      if (tid < 9) {
+        const int base = incl - n;
+        sh.rowLo[r] = lo; sh.rowHi[r] = lo + n; sh.rowBase[r] = base;
+        sh.segDelta[tid] = lo - base;
+        sh.segEnd[tid] = incl;
+      }
+      if (tid == 0) { sh.total = total; sh.winOk = winOk ? 1 : 0; }
+    } else if (tid == 0) {  // small batch that still does not fit (very dense cells): drop runs, serially (rare)
       int base = 0;
-      // the own row (4) first, then the others: if LDS still runs out, the most-used runs are the ones that are staged
-      const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
       for (int q = 0; q < 9; q++) {
-        const int r = order[q];
-        int n = sh.rowHi[r] - sh.rowLo[r];
-        sh.rowBase[r] = base;
-        if (base + n > FN_CAND_CAP) { sh.rowHi[r] = sh.rowLo[r]; n = 0; atomicAdd(&d.dbg[3], 1u); }  // not staged (rare)
-        sh.segDelta[q] = sh.rowLo[r] - base;
-        base += n;
+        const int rr = order[q];
+        const int l = sh.win[rr][0], hh = winOk ? sh.win[rr][nc] : sh.win[rr][1];
+        int nn = max(hh, l) - l;
+        sh.rowLo[rr] = l; sh.rowBase[rr] = base;
+        if (base + nn > FN_CAND_CAP) { nn = 0; atomicAdd(&d.dbg[3], 1u); }  // not staged
+        sh.rowHi[rr] = l + nn;
+        sh.segDelta[q] = l - base;
+        base += nn;
         sh.segEnd[q] = base;
       }
-      sh.total = base;
+      sh.total = base; sh.winOk = winOk ? 1 : 0;
     }
   }
   __syncthreads();
+  FN_STAMP(2)
   if (sh.retry == 2) {  // uniform
     __syncthreads();
     if (tid == 0) sh.retry = 1;
@@ -202,7 +339,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     for (int q = 0; q < 8; q++) se[q] = sh.segEnd[q];
 #pragma unroll
     for (int q = 0; q < 9; q++) sd[q] = sh.segDelta[q];
-    constexpr int PER = 8;  // records per thread and round, all loads of a round in flight together
+    constexpr int PER = 6;  // records per thread and round, all loads of a round in flight together (3072 per round)
 #pragma unroll 1
     for (int f0 = 0; f0 < total; f0 += PER * FN_THREADS) {
       float4 rec[PER];
@@ -222,77 +359,80 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
     }
   }
   __syncthreads();
+  FN_STAMP(3)
   if (tid == 0) sh.batchLo = batchHi;  // next batch (every thread has read batchLo / batchHi by now)
   const bool mine_now = alive && id >= batchLo && id < batchHi;  // this lane's particle belongs to the current batch
-  if (!mine_now) continue;
 
-  float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mine_now) {  // (whole quads: the four lanes of a particle agree)
+  // (opaque to the optimiser: everything derived from the particle's record is otherwise hoisted out of the batch loop,
+  // which runs once for almost every workgroup, and then spilled)
+  float4 me = myPos;
+  int myCellNow = myCell, idNow = id;
+  asm volatile("" : "+v"(me.x), "+v"(me.y), "+v"(me.z), "+v"(myCellNow), "+v"(idNow));
   bool slow = false;
-  int ldsLo[4], num[4], absDelta[4];  // absDelta: sorted index = LDS slot + absDelta
+  int pLo[4], pHi[4], absDelta[4];  // this lane's four pieces as LDS slot ranges; sorted index = LDS slot + absDelta
   int selfSlot = -1;
+  {  // the lane's four cells (sphFluid.cl:253-308) with the cell table read from the LDS window where possible
+    const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
+    const float cfx = (float)(int)(me.x * d.cellSizeInv) * d.cellSize;
+    const float cfy = (float)(int)(me.y * d.cellSizeInv) * d.cellSize;
+    const float cfz = (float)(int)(me.z * d.cellSizeInv) * d.cellSize;
+    const int dx = ((px - cfx) < d.h) ? -1 : 1;  // -1: the particle sits in the low half of its cell
+    const int dy = ((py - cfy) < d.h) ? -1 : 1;
+    const int dz = ((pz - cfz) < d.h) ? -1 : 1;
+    const int sy = dy * d.gx, sz = dz * d.gx * d.gy;
+    const int ry = dy + 1, rz = dz + 1;  // staged-row ids: row = (y step + 1) + 3 * (z step + 1)
+    const bool useWin = sh.winOk != 0;
+    // pair A: cells 0 (own), 5 (xz), 6 (yz), 7 (xyz); pair B: cells 1 (x), 2 (y), 3 (z), 4 (xy)
+    const bool stepX[4] = {pairB != 0, pairB == 0, false, true};
+    const bool stepY[4] = {false, pairB != 0, pairB == 0, true};
+    const bool stepZ[4] = {false, pairB == 0, true, pairB == 0};
 #pragma unroll
-  for (int i = 0; i < 4; i++) { num[i] = 0; ldsLo[i] = 0; absDelta[i] = 0; }
-  if (alive) {
-    me = myPos;
-    CellSet cs;
-    {  // particle_cells() with the cell table read from the LDS window where possible
-      const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
-      const float cfx = (float)(int)(me.x * d.cellSizeInv) * d.cellSize;
-      const float cfy = (float)(int)(me.y * d.cellSizeInv) * d.cellSize;
-      const float cfz = (float)(int)(me.z * d.cellSizeInv) * d.cellSize;
-      const int dx = ((px - cfx) < d.h) ? -1 : 1;
-      const int dy = ((py - cfy) < d.h) ? -1 : 1;
-      const int dz = ((pz - cfz) < d.h) ? -1 : 1;
-      const int sy = dy * d.gx, sz = dz * d.gx * d.gy;
-      const int off[8] = {0, dx, sy, sz, dx + sy, dx + sz, sy + sz, dx + sy + sz};
-      const int xs[8] = {0, dx, 0, 0, dx, dx, 0, dx};  // the x part of off[]: position inside the row's window
-      const int ry = dy + 1, rz = dz + 1;
-      const int rows[8] = {4, 4, ry + 3, 1 + 3 * rz, ry + 3, 1 + 3 * rz, ry + 3 * rz, ry + 3 * rz};
-      const bool useWin = sh.winOk != 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int raw = myCell + off[k];
-        const int c = wrap_cell(raw, d.G);
-        if (c == raw && useWin) {
-          const int i = myCell - cLo + 1 + xs[k];  // in [0, nc): the batch's cells are cLo..cHi, the window starts at cLo-1
-          cs.row[k] = rows[k];
-          cs.lo[k] = sh.win[rows[k]][i];
-          cs.hi[k] = sh.win[rows[k]][i + 1];
-        } else {  // wrapped cells (never staged: only their emptiness matters) and batches wider than the window
-          const int cc = min(max(c, 0), d.G - 1);
-          cs.row[k] = (c == raw) ? rows[k] : -1;
-          cs.lo[k] = (int)d.cellStart[cc];
-          cs.hi[k] = (int)d.cellStart[cc + 1];
-        }
+    for (int i = 0; i < 4; i++) {
+      const int xs = stepX[i] ? dx : 0;
+      const int raw = myCellNow + xs + (stepY[i] ? sy : 0) + (stepZ[i] ? sz : 0);
+      const int row = (stepY[i] ? ry : 1) + 3 * (stepZ[i] ? rz : 1);
+      const int c = wrap_cell(raw, d.G);
+      int lo, hi;
+      bool staged = c == raw;  // wrapped cells are never staged: only their emptiness matters
+      if (staged && useWin) {
+        const int w = myCellNow - cLo + 1 + xs;  // in [0, nc): the batch's cells are cLo..cHi, the window starts at cLo-1
+        lo = sh.win[row][w];
+        hi = sh.win[row][w + 1];
+      } else {  // wrapped cells and batches wider than the window
+        const int cc = min(max(c, 0), d.G - 1);
+        lo = (int)d.cellStart[cc];
+        hi = (int)d.cellStart[cc + 1];
       }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int n = cs.hi[k] - cs.lo[k];
+      const int n = hi - lo;
       int base = 0;
       if (n > 0) {
-        const int r = cs.row[k];
-        if (r >= 0 && cs.lo[k] >= sh.rowLo[r] && cs.hi[k] <= sh.rowHi[r]) base = sh.rowBase[r] + (cs.lo[k] - sh.rowLo[r]);
-        else slow = true;  // a non-empty cell of this particle is not in LDS (both lanes of the pair see this)
+        if (staged && lo >= sh.rowLo[row] && hi <= sh.rowHi[row]) base = sh.rowBase[row] + (lo - sh.rowLo[row]);
+        else slow = true;  // a non-empty cell of this particle is not in LDS
       }
-      // lane 0 of the pair walks cells {0,5,6,7}, lane 1 cells {1,2,3,4}: both get four cells and about half of the hits
-      // (own cell ~42 %, each face neighbour ~14 %, edge ~5 %, corner ~2 %), so neither list is much longer than the other
-      const int owner = (k == 0 || k >= 5) ? 0 : 1, slot = (k == 0) ? 0 : (k >= 5 ? k - 4 : k - 1);
-      if (owner == half) { num[slot] = n; ldsLo[slot] = base; absDelta[slot] = cs.lo[k] - base; }
-      if (k == 0 && half == 0) selfSlot = base + (id - cs.lo[0]);  // the particle itself sits in its own cell
+      // halves: the split point is rounded to a 16-byte boundary of the SoA arrays so the second half starts aligned
+      const int mid = min(base + n, max(base, (base + (n >> 1) + 2) & ~3));
+      pLo[i] = sub ? mid : base;
+      pHi[i] = sub ? base + n : mid;
+      absDelta[i] = lo - base;
+      if (i == 0 && pairB == 0) selfSlot = base + (idNow - lo);  // the particle itself sits in its own cell
     }
+  }
+  {  // both pairs must agree (inside a pair the lanes see the same cells). The DPP move is executed by ALL four lanes — under a
+     // short-circuit `||` the lanes that are already slow would sit it out and their partners would read 0 from them.
+    const int otherPair = quad_xor2((int)slow);
+    slow = slow || (otherPair != 0);
   }
   if (slow) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) num[i] = 0;
-    if (half == 0) atomicAdd(&d.dbg[0], 1u);
+    for (int i = 0; i < 4; i++) pHi[i] = pLo[i];
+    if (quadLane == 0) atomicAdd(&d.dbg[0], 1u);
   }
+  FN_STAMP(4)
 
   // ---- 1. single walk with the cheap filter; r_max covers pass 0 (h) and every possible pass-1 radius (<= 31h/30).
-  // Four candidates per trip from 16-byte-aligned SoA reads (the walk starts at the aligned slot at or before the cell and
-  // masks what lies outside [0, n)); the arithmetic is packed f32 (v_pk_*), IEEE per component, same order as the reference.
-  const float rA = d.h, rB = (float)(SPH_RSEG + 1) * d.h / (float)SPH_RSEG;
-  const float r2max = fmaxf(rA * rA, rB * rB);
+  // Four candidates per trip from 16-byte-aligned SoA reads (the walk starts at the aligned slot at or before the piece and
+  // masks what lies outside it); the arithmetic is packed f32 (v_pk_*), IEEE per component.
   int cnt = 0;
   int segEnd[4];
   const f32x2 mx = {me.x, me.x}, my = {me.y, me.y}, mz = {me.z, me.z};
@@ -300,8 +440,8 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   // expressions), so it may use fused multiply-adds: its d^2 differs from the reference's by < 2^-21 relative, which the
   // 2^-20 margin on the radius absorbs. A hit is the SIGN BIT of d^2 - r^2 (two distinct floats never subtract to zero with
   // denormals on), shifted into a per-lane bit mask with one v_alignbit per candidate; every 32 candidates, and at the end
-  // of a cell, the few set bits are turned into list entries in traversal order.
-  const float r2f = r2max * (1.f + 0x1p-20f);
+  // of a piece, the few set bits are turned into list entries in traversal order.
+  const float r2f = sh.binU[63];  // max(h, 31h/30)^2 * (1 + 2^-20), computed on the host
   const f32x2 thr = {r2f, r2f};
 #define FN_LOAD(a, X, Y, Z)                                                                     \
   const f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);                                    \
@@ -323,9 +463,9 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
 #define FN_FLUSH(k)                                                                             \
   {                                                                                             \
     uint32_t m = ((k) == 0) ? 0u : (acc << (32 - (k)));   /* candidate t at bit 31 - t */       \
-    const int lowT = cellLo - aBase, hiT = cellHi - aBase;                                      \
-    if (lowT > 0) m &= 0xffffffffu >> lowT;               /* slots before the cell (first chunk) */ \
-    if (hiT < 32) m &= ~(0xffffffffu >> hiT);             /* slots past the cell */             \
+    const int lowT = pieceLo - aBase, hiT = pieceHi - aBase;                                    \
+    if (lowT > 0) m &= 0xffffffffu >> lowT;               /* slots before the piece (first chunk) */ \
+    if (hiT < 32) m &= ~(0xffffffffu >> hiT);             /* slots past the piece */            \
     if (i == 0) {                                         /* the particle itself */             \
       const unsigned ts = (unsigned)(selfSlot - aBase);                                         \
       if (ts < 32u) m &= ~(0x80000000u >> ts);                                                  \
@@ -339,18 +479,17 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int n = num[i], cellLo = ldsLo[i], cellHi = cellLo + n;
-    if (n > 0) {
-      int a = cellLo & ~3;  // aligned slot at or before the cell
+    const int pieceLo = pLo[i], pieceHi = pHi[i];
+    if (pieceHi > pieceLo) {
+      int a = pieceLo & ~3;  // aligned slot at or before the piece
       int aBase = a, k = 0;
       uint32_t acc = 0u;
       f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);
       f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);
       f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
-      while (a < cellHi) {
-        // two quads per trip, ping-pong: the next quad's three LDS reads are issued before the current quad is tested
-        // (the wave has only one partner on its SIMD to hide LDS latency). Reads and tests may run up to 11 slots past
-        // the cell (FN_CAND_PAD); FN_FLUSH masks those bits.
+      while (a < pieceHi) {
+        // two quads per trip, ping-pong: the next quad's three LDS reads are issued before the current quad is tested.
+        // Reads and tests may run up to 11 slots past the piece (FN_CAND_PAD); FN_FLUSH masks those bits.
         FN_LOAD(a + 4, Xb, Yb, Zb)
         FN_TEST(X, Y, Z)
         X = *reinterpret_cast<const f32x4*>(&sh.x[a + 8]);
@@ -367,18 +506,19 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
 #undef FN_LOAD
 #undef FN_TEST
 #undef FN_FLUSH
-  bool over = cnt > FN_LIST_CAP;
-  const int partnerOver = __shfl_xor((int)over, 1);  // unconditional: both lanes of the pair must take part in the swap
-  over = over || (partnerOver != 0);
+  FN_STAMP(5)
+  int over = cnt > FN_LIST_CAP ? 1 : 0;
+  over |= quad_xor1(over);  // all four lanes of the quad take part
+  over |= quad_xor2(over);
   if (over) {
-    if (half == 0 && !slow) atomicAdd(&d.dbg[1], 1u);
+    if (quadLane == 0 && !slow) atomicAdd(&d.dbg[1], 1u);
     slow = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) segEnd[i] = 0;
   }
 
-  // ---- 2. replay of the reference's two passes over the short lists, entirely in registers: the list (<= 48 LDS slots
-  // per lane) is expanded once into d2v[] with static indices (the slots are re-read from LDS for the few hits that are stored), 8 entries at a time with a wave-uniform skip.
+  // ---- 2. replay of the reference's two passes over the short lists, entirely in registers: the list (<= 24 LDS slots
+  // per lane) is expanded once into d2v[] with static indices, 8 entries at a time with a wave-uniform skip.
   const int total = segEnd[3];
   float d2v[FN_LIST_CAP];
 #pragma unroll
@@ -399,6 +539,7 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
       for (int u = 0; u < 8; u++) d2v[c0 + u] = __builtin_inff();
     }
   }
+  FN_STAMP(6)
   // ---- 2a. pass 0 + threshold (sphFluid.cl:157-161,310-323) without building the histogram: C(j) = number of hits in
   // bins 0..j = number of hits with d^2 < U[j] (U precomputed exactly on the host). The reference's loop stops at
   // j* = min{ j : C(j) >= 32 } with jb = j* if C(j*) == 32, j* - 1 if it overshoots, and jb = 30 if no such j exists.
@@ -418,58 +559,66 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
         for (int u = 0; u < 8; u++) c += (d2v[c0 + u] < U) ? 1 : 0;
       }
     }
-    c += __shfl_xor(c, 1);
+    c += quad_xor1(c);
+    c += quad_xor2(c);
     if (lo < hi) {
       if (c >= SPH_MAXN) { hi = mid; cAtHi = c; } else lo = mid + 1;
     }
   }
   const int jb = (lo >= SPH_RSEG) ? SPH_RSEG : ((cAtHi == SPH_MAXN) ? lo : lo - 1);
-  const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
-  const float r2 = r_thr * r_thr;
+  const float r2 = sh.binU[32 + jb];  // r_thr^2 with r_thr = (float)(jb + 1) * h / 30 (sphFluid.cl:313-321), from the host
+  FN_STAMP(7)
 
-  // ---- 2b. pass 1: hits with d^2 <= r_thr^2 as a bit mask; per-cell counts by popcount; swap the four counts inside the
-  // pair; every hit goes to (hits in earlier cells of the merged order) + (rank inside its cell). Slots >= 32 are
-  // dropped, which is what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
-  unsigned long long acc = 0ull;
+  // ---- 2b. pass 1: hits with d^2 <= r_thr^2 as a bit mask; per-piece counts by popcount, exchanged inside the quad as one
+  // packed word; every hit goes to (hits in earlier pieces of the merged order) + (rank inside its piece). Slots >= 32
+  // are dropped, which is what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
+  uint32_t acc = 0u;
 #pragma unroll
   for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
     if (c0 < liveEnd) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc |= (d2v[c0 + u] <= r2) ? (1ull << (c0 + u)) : 0ull;
+      for (int u = 0; u < 8; u++) acc |= (d2v[c0 + u] <= r2) ? (1u << (c0 + u)) : 0u;
     }
   }
-  unsigned long long below[4];  // bits of the entries before the end of cell i
+  uint32_t below[4];  // bits of the entries before the end of piece i
 #pragma unroll
-  for (int i = 0; i < 4; i++) below[i] = (segEnd[i] >= 64) ? ~0ull : ((1ull << segEnd[i]) - 1ull);
-  int mine[4], theirs[4];
-  mine[0] = __popcll(acc & below[0]);
+  for (int i = 0; i < 4; i++) below[i] = (segEnd[i] >= 32) ? ~0u : ((1u << segEnd[i]) - 1u);
+  int mine[4];
+  mine[0] = __popc(acc & below[0]);
 #pragma unroll
-  for (int i = 1; i < 4; i++) mine[i] = __popcll(acc & below[i] & ~below[i - 1]);
-#pragma unroll
-  for (int i = 0; i < 4; i++) theirs[i] = __shfl_xor(mine[i], 1);
-  if (alive && !slow) {
-    // merged (reference) order of the 8 cells: A0 | B1 B2 B3 B4 | A5 A6 A7, where A = lane 0 and B = lane 1 of the pair
+  for (int i = 1; i < 4; i++) mine[i] = __popc(acc & below[i] & ~below[i - 1]);
+  const int packed = mine[0] | (mine[1] << 8) | (mine[2] << 16) | (mine[3] << 24);  // each <= 24
+  const int partner = quad_xor1(packed);        // the other half of the same four cells
+  const int cellTot = packed + partner;         // whole-cell counts of this pair (bytes <= 48: no carry)
+  const int otherTot = quad_xor2(cellTot);      // whole-cell counts of the other pair
+  if (!slow) {
+    const int c0b = cellTot & 255, c1b = (cellTot >> 8) & 255, c2b = (cellTot >> 16) & 255, c3b = (cellTot >> 24) & 255;
+    const int o0b = otherTot & 255;
+    const int sumOther = o0b + ((otherTot >> 8) & 255) + ((otherTot >> 16) & 255) + ((otherTot >> 24) & 255);
+    const int run = c0b + c1b + c2b + c3b + sumOther;
+    // pair A (cells 0 | 5 6 7): cell 0 starts at 0, cells 5.. after cell 0 and all of pair B;
+    // pair B (cells 1 2 3 4): starts after cell 0 (= pair A's first cell)
+    const int first = pairB ? o0b : 0, afterFirst = pairB ? 0 : sumOther;
     int start[4];
-    const int sumMine = mine[0] + mine[1] + mine[2] + mine[3], sumTheirs = theirs[0] + theirs[1] + theirs[2] + theirs[3];
-    const int run = sumMine + sumTheirs;
-    if (half == 0) { start[0] = 0; start[1] = mine[0] + sumTheirs; }
-    else { start[0] = theirs[0]; start[1] = start[0] + mine[0]; }
-    start[2] = start[1] + mine[1];
-    start[3] = start[2] + mine[2];
-    // walk the entries in list order with a running (cell start, index delta, rank inside the cell)
+    start[0] = first + (sub ? (partner & 255) : 0);
+    start[1] = first + c0b + afterFirst + (sub ? ((partner >> 8) & 255) : 0);
+    start[2] = first + c0b + afterFirst + c1b + (sub ? ((partner >> 16) & 255) : 0);
+    start[3] = first + c0b + afterFirst + c1b + c2b + (sub ? ((partner >> 24) & 255) : 0);
+    // walk the entries in list order with a running (piece start, index delta, rank inside the piece)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
-    int32_t* const idBase = d.nbrId + (((size_t)(id >> 6) * 8 * 64 + (size_t)(id & 63)) << 2);
-    float* const distBase = d.nbrDist + (((size_t)(id >> 6) * 8 * 64 + (size_t)(id & 63)) << 2);
+    const size_t mapBase = ((size_t)(idNow >> 6) * 8 * 64 + (size_t)(idNow & 63)) << 2;
+    int32_t* const idBase = d.nbrId + mapBase;
+    float* const distBase = d.nbrDist + mapBase;
 #pragma unroll
     for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
       if (!__any(c0 < total)) continue;  // wave-uniform skip of empty chunks
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int e = c0 + u;
-        if (e == segEnd[0]) { curStart = start[1]; curDelta = absDelta[1]; rank = 0; }  // (empty cells cascade in order)
+        if (e == segEnd[0]) { curStart = start[1]; curDelta = absDelta[1]; rank = 0; }  // (empty pieces cascade in order)
         if (e == segEnd[1]) { curStart = start[2]; curDelta = absDelta[2]; rank = 0; }
         if (e == segEnd[2]) { curStart = start[3]; curDelta = absDelta[3]; rank = 0; }
-        if ((acc >> e) & 1ull) {
+        if ((acc >> e) & 1u) {
           const int pos = curStart + rank;
           rank++;
           if (pos < SPH_MAXN) {
@@ -480,99 +629,50 @@ __global__ __launch_bounds__(FN_THREADS, 2) void k_find_neighbors(SphDev d, uint
         }
       }
     }
-    for (int k = min(run, SPH_MAXN) + half; k < SPH_MAXN; k += 2) {  // K1 folded in: unused slots = (-1, -1)
-      const size_t idx = nbr_index(id, k);
+    for (int k = min(run, SPH_MAXN) + quadLane; k < SPH_MAXN; k += FN_LANES) {  // K1 folded in: unused slots = (-1, -1)
+      const size_t idx = nbr_index(idNow, k);
       d.nbrId[idx] = -1;
       d.nbrDist[idx] = -1.f;
     }
   }
-  // ---- the rare particles the fast path cannot serve are queued for k_find_neighbors_fallback (exact, any input)
-  if (alive && slow && half == 0) slowQueue[atomicAdd(&d.dbg[4], 1u)] = (uint32_t)id;
-  }  // batches
-}
+  // ---- the rare particles the fast path cannot serve are left to the exact wave-per-particle walk below
+  if (slow && quadLane == 0) sh.slowList[atomicAdd(&sh.nSlow, 1)] = idNow;
+  FN_STAMP(8)
+  }  // mine_now
 
-// The queued particles, one WAVE per particle: the 64 lanes take consecutive candidates of a cell, so a particle costs
-// ~2 x 8 x 2 dependent memory round trips instead of ~1300. The reference's semantics, literally: pass 0 fills a
-// 30-bin histogram (LDS atomics), every lane derives the same r_thr, pass 1 assigns slots in traversal order with a
-// ballot prefix (lane order == candidate order inside a chunk) and stops at 32.
-__global__ __launch_bounds__(SPH_BLOCK) void k_find_neighbors_fallback(SphDev d, const uint32_t* __restrict__ slowQueue) {
-  __shared__ uint32_t hist[SPH_BLOCK / 64][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t count = d.dbg[4];
-  const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (uint32_t q = blockIdx.x * (SPH_BLOCK / 64) + wave; q < count; q += gridDim.x * (SPH_BLOCK / 64)) {
-    const int id = (int)slowQueue[q];
-    const float4 me = d.sortedPos[id];
-    CellSet cs;
-    particle_cells(d, me, (int)d.keys[id], cs);
-    if (lane < 32) hist[wave][lane] = 0u;
-    const float h2 = d.h * d.h;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      for (int j0 = cs.lo[k]; j0 < cs.hi[k]; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < cs.hi[k] && j != id) {
-          const float4 o = d.sortedPos[j];
-          const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-          const float d2 = ex * ex + ey * ey + ez * ez;
-          if (d2 <= h2) {
-            const float dist = sqrtf(d2);
-            const int bin = (int)(dist * (float)SPH_RSEG / d.h);
-            if (bin < SPH_RSEG) atomicAdd(&hist[wave][bin], 1u);
-          }
-        }
-      }
-    }
-    int jb = 0, sum = 0;  // threshold, sphFluid.cl:310-323 (LDS ops of one wave retire in order: the adds are visible)
-    while (jb < SPH_RSEG) {
-      sum += (int)hist[wave][jb];
-      if (sum == SPH_MAXN) break;
-      if (sum > SPH_MAXN) { jb--; break; }
-      jb++;
-    }
-    const float r_thr = (float)(jb + 1) * d.h / (float)SPH_RSEG;
-    const float r2 = r_thr * r_thr;
-    int found = 0;  // wave-uniform
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      for (int j0 = cs.lo[k]; j0 < cs.hi[k] && found < SPH_MAXN; j0 += 64) {
-        const int j = j0 + lane;
-        float d2 = 0.f;
-        bool hit = false;
-        if (j < cs.hi[k] && j != id) {
-          const float4 o = d.sortedPos[j];
-          const float ex = me.x - o.x, ey = me.y - o.y, ez = me.z - o.z;
-          d2 = ex * ex + ey * ey + ez * ez;
-          hit = d2 <= r2;
-        }
-        const unsigned long long m = __ballot(hit);
-        const int pos = found + __popcll(m & ltMask);
-        if (hit && pos < SPH_MAXN) {
-          const size_t idx = nbr_index(id, pos);
-          d.nbrId[idx] = j;
-          d.nbrDist[idx] = sqrtf(d2) * d.simScale;
-        }
-        found += __popcll(m);
-      }
-    }
-    if (lane >= min(found, SPH_MAXN) && lane < SPH_MAXN) {
-      const size_t idx = nbr_index(id, lane);
-      d.nbrId[idx] = -1;
-      d.nbrDist[idx] = -1.f;
-    }
+  __syncthreads();
+  {
+    const int nSlow = sh.nSlow;  // uniform
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int s = wave; s < nSlow; s += FN_WAVES) fn_exact_walk(d, sh, sh.slowList[s], wave, lane);
   }
+  FN_STAMP(9)
+  }  // batches
+#ifdef FN_STAMPS
+  __syncthreads();
+  if (tid < 16) atomicAdd(&d.dbg[16 + tid], sh.stamps[tid] >> 6);
+#endif
 }
 
 int sphk_find_neighbors(sph_solver* s, int ghostDepth) {
-  static bool attrSet = false;
-  if (!attrSet) {
-    SPH_HIP(hipFuncSetAttribute((const void*)k_find_neighbors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FnShared)));
-    attrSet = true;
+  {  // opt in to > 64 KB of dynamic LDS once per DEVICE (the attribute lives on the device's function object)
+    static std::mutex mu;
+    static bool attrSet[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev = s->cfg.device;
+    if (dev < 0 || dev >= 64 || !attrSet[dev]) {
+      SPH_HIP(hipFuncSetAttribute((const void*)k_find_neighbors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FnShared)));
+      if (dev >= 0 && dev < 64) attrSet[dev] = true;
+    }
   }
-  // the fallback queue reuses keysAlt (N words, idle between the sort and the next step's sort)
-  SPH_HIP(hipMemsetAsync(&s->d.dbg[4], 0, sizeof(uint32_t), s->stream));
-  hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, sph_ranged(s, ghostDepth), s->d.keysAlt);
-  hipLaunchKernelGGL(k_find_neighbors_fallback, dim3(min(sph_blocks(s->d.N, 4), 1024)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->d.keysAlt);
+  const SphDev r = sph_ranged(s, ghostDepth);
+  FnParams a;
+  a.G = r.G; a.gx = r.gx; a.gy = r.gy; a.rangeLo = r.rangeLo; a.rangeHi = r.rangeHi;
+  a.h = r.h; a.cellSize = r.cellSize; a.cellSizeInv = r.cellSizeInv; a.simScale = r.simScale;
+  a.xmin = r.xmin; a.ymin = r.ymin; a.zmin = r.zmin;
+  a.sortedPos = r.sortedPos; a.keys = r.keys; a.cellStart = r.cellStart;
+  a.nbrId = r.nbrId; a.nbrDist = r.nbrDist; a.binU = r.binU; a.dbg = r.dbg;
+  hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, a);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }

@@ -19,3 +19,12 @@ print("bad cells", np.unique(cells[bad])[:20], "count per cell of bad", np.binco
 for p in bad[:3]:
     print("p", p, "cell", cells[p], "got", a[p][:8], "want", b[p][:8], "n got", (a[p] >= 0).sum(), "n want", (b[p] >= 0).sum())
     print("   got cells", cells[a[p][a[p] >= 0]][:8], "want cells", cells[b[p][b[p] >= 0]][:8])
+da = hip.buffer("neighborMap").reshape(-1, 32, 2)[:, :, 1]; db = ora.buffer("neighborMap").reshape(-1, 32, 2)[:, :, 1]
+badd = np.flatnonzero((da.view(np.uint32) != db.view(np.uint32)).any(1))
+print("particles with a distance mismatch", badd.size, badd[:20])
+print("bad sorted ids mod 128:", bad % 128, " // 128:", bad // 128)
+sp = ora.buffer("sortedPosition").reshape(-1, 4)[:N]
+for p in bad[:6]:
+    print("p", p, "type", sp[p, 3] if False else "", "pos", sp[p, :3], "cell", cells[p], "occ", occ[cells[p]])
+    print("   got ", a[p]); print("   want", b[p])
+    print("   dgot ", da[p][:12]); print("   dwant", db[p][:12])

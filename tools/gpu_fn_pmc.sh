@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU-box script: SQ counter passes + phase stamps of findNeighbors on the config #2 cube. Usage: tools/gpu_fn_pmc.sh TAG
+set -o pipefail
+TAG=${1:-run}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout -k 10 120 python tools/time_find_neighbors.py 20 | tee $OUT/fn_time.txt
+if [ -f smoothed-particle-hydrodynamics_amd/libsphmi_stamps.so ]; then timeout -k 10 120 python tools/fn_phase_shares.py 5 | tee $OUT/fn_phases.txt; fi
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  --output-format csv -d $OUT/pmcA -- python3 tools/time_find_neighbors.py 5 > $OUT/pmcA.log 2>&1 || { tail -20 $OUT/pmcA.log; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD \
+  --output-format csv -d $OUT/pmcB -- python3 tools/time_find_neighbors.py 5 > $OUT/pmcB.log 2>&1 || { tail -20 $OUT/pmcB.log; exit 1; }
+python tools/pmc_table.py $OUT/pmcA/*/*counter_collection.csv > $OUT/pmc_SQ_A.txt
+python tools/pmc_table.py $OUT/pmcB/*/*counter_collection.csv > $OUT/pmc_SQ_B.txt
+grep -E "kernel|find_neighbors" $OUT/pmc_SQ_A.txt $OUT/pmc_SQ_B.txt
+rm -rf $OUT/pmcA $OUT/pmcB
