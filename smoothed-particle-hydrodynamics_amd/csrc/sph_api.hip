@@ -221,7 +221,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   if (cfg->abi_version != SPHMI_ABI_VERSION) { sph_set_error("sph_config.abi_version %d != %d", cfg->abi_version, SPHMI_ABI_VERSION); return SPH_ERR_INVALID; }
   const int N = cfg->particleCount;
   const int cap = cfg->capacity > 0 ? cfg->capacity : N;
-  if (N <= 0 || cap < N || (long long)cap * 32 >= 0x7fffffffLL * 4LL) { sph_set_error("particleCount %d / capacity %d out of range", N, cap); return SPH_ERR_INVALID; }
+  if (N <= 0 || cap < N || (long long)cap * 32 >= 0x100000000LL) { sph_set_error("particleCount %d / capacity %d out of range", N, cap); return SPH_ERR_INVALID; }
   if (cfg->gridCellsX <= 0 || cfg->gridCellsY <= 0 || cfg->gridCellsZ <= 0 ||
       (long long)cfg->gridCellsX * cfg->gridCellsY * cfg->gridCellsZ != (long long)cfg->gridCellCount) {
     sph_set_error("gridCellCount does not equal gridCellsX*gridCellsY*gridCellsZ");
@@ -616,7 +616,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   const size_t n = (size_t)d.N, G1 = (size_t)d.G + 1;
   const int numTiles = (d.N + SPH_TILE - 1) / SPH_TILE;
   size_t need = 0;
-  enum { B_POS, B_VEL, B_SPOS, B_SVEL, B_ACC, B_NMAP, B_NIDS, B_PI, B_PIB, B_GCI, B_GCIF, B_P, B_RHO, B_DBG } which;
+  enum { B_POS, B_VEL, B_SPOS, B_SVEL, B_ACC, B_NMAP, B_NIDS, B_PI, B_PIB, B_GCI, B_GCIF, B_P, B_RHO, B_DBG, B_TRACE } which;
   if (!strcmp(name, "position")) { which = B_POS; need = sizeof(float4) * 2 * n; }
   else if (!strcmp(name, "velocity")) { which = B_VEL; need = sizeof(float4) * 2 * n; }
   else if (!strcmp(name, "sortedPosition")) { which = B_SPOS; need = sizeof(float4) * 2 * n; }
@@ -630,6 +630,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   else if (!strcmp(name, "gridCellIndexFixedUp")) { which = B_GCIF; need = sizeof(uint32_t) * G1; }
   else if (!strcmp(name, "pressure")) { which = B_P; need = sizeof(float) * n; }
   else if (!strcmp(name, "rho")) { which = B_RHO; need = sizeof(float) * 2 * n; }
+  else if (!strcmp(name, "diagnosticTrace")) { which = B_TRACE; need = sizeof(uint32_t) * n; }  // scratch words of diagnostic builds
   else if (!strcmp(name, "debugCounters")) { which = B_DBG; need = sizeof(uint32_t) * SPH_DBG_WORDS; }
   else { sph_set_error("unknown buffer '%s'", name); return SPH_ERR_UNKNOWN_BUFFER; }
   if (needed) *needed = need;
@@ -689,6 +690,7 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
     case B_GCI: rc = d2h(s, o, d.cellStartRaw, sizeof(uint32_t) * G1); break;
     case B_GCIF: rc = d2h(s, o, d.cellStart, sizeof(uint32_t) * G1); break;
     case B_P: rc = d2h(s, o, d.pressure, sizeof(float) * n); break;
+    case B_TRACE: rc = d2h(s, o, d.valsAlt, sizeof(uint32_t) * n); break;
     case B_DBG: rc = d2h(s, o, d.dbg, sizeof(uint32_t) * SPH_DBG_WORDS); break;
     case B_RHO:
       rc = d2h(s, o, d.rho, sizeof(float) * n);

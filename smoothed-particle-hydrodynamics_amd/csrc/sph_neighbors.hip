@@ -48,16 +48,17 @@ int sphk_clear_neighbors(sph_solver* s) {
   return SPH_OK;
 }
 
-// What the search kernel needs of SphDev (a by-value SphDev costs ~100 SGPRs, half of them spilled).
+// What the search kernel needs of SphDev (a by-value SphDev costs ~100 SGPRs, half of them spilled). The arrays are separate
+// `__restrict__` kernel arguments so that loads with a workgroup-uniform address become scalar loads.
 struct FnParams {
   int G, gx, gy, rangeLo, rangeHi;
   float h, cellSize, cellSizeInv, simScale, xmin, ymin, zmin;
+};
+struct FnArrays {  // (what the exact walk needs; built inside the kernel from its arguments)
   const float4* sortedPos;
   const uint32_t *keys, *cellStart;
   int32_t* nbrId;
   float* nbrDist;
-  const float* binU;  // [0..31] pass-0 thresholds U[j]; [32..62] pass-1 radii r_thr(jb)^2, jb = 0..30; [63] the filter radius^2
-  uint32_t* dbg;
 };
 
 __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFluid.cl:94-112
@@ -74,7 +75,7 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
 #define FN_CAND_CAP 4096          // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
 #endif
 #define FN_WIN 16                 // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
-#define FN_CAND_PAD 12            // the aligned, prefetching 4-wide walk reads (never uses) up to 11 slots past a piece
+#define FN_CAND_PAD 16            // the aligned, prefetching 4-wide walk reads (never uses) up to 15 slots past a piece
 #ifndef FN_LIST_CAP
 #define FN_LIST_CAP 24            // compaction list entries per lane (u16 [entry][lane]); 96 per particle
 #endif
@@ -82,22 +83,22 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define FN_DST_STRIDE 36           // floats per particle in the d^2 staging area (32 slots + 16 B: keeps rows 16-byte aligned)
+
 struct FnShared {
   float x[FN_CAND_CAP + FN_CAND_PAD], y[FN_CAND_CAP + FN_CAND_PAD], z[FN_CAND_CAP + FN_CAND_PAD];  // staged candidates
-  uint16_t list[FN_LIST_CAP][FN_THREADS];         // [entry][lane] LDS slots of the filter hits, traversal order
+  // per wave: [entry][lane] LDS slots of the filter hits, traversal order. Once a wave has expanded its lists into registers the
+  // same 3 KB hold the d^2 of the accepted neighbours, [particle of the wave][slot], on their way to 16-byte map stores.
+  uint16_t list[FN_WAVES][FN_LIST_CAP][64];
   float binU[64];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j; r_thr^2 table; filter radius (see SphDev::binU)
   int rowLo[9], rowHi[9], rowBase[9];             // staged runs: sorted-index range and first LDS slot
   int win[9][FN_WIN];                             // cellStart[] of the cells cLo-1 .. of every row (see the staging code)
-  int segEnd[9], segDelta[9];                     // flat staging: LDS slots < segEnd[q] belong to run q; sorted index = slot + segDelta[q]
-  int total, winOk;                               // staged candidates; 1 if the window covers the batch's cells
-  int batchLo, batchHi, retry;                    // current batch of particles; retry: small-batch mode
-  int nSlow;                                      // particles of this batch left to the exact wave-per-particle walk
-  int slowList[FN_PART];
   uint32_t hist[FN_WAVES][32];                    // radial histograms of the wave-per-particle walk
 #ifdef FN_STAMPS
   uint32_t stamps[16];                            // diagnostic build: cycles per phase, summed over the workgroup's waves
 #endif
 };
+static_assert(16 * FN_DST_STRIDE * 4 <= FN_LIST_CAP * 64 * 2, "d^2 staging must fit the wave's list area");
 
 // DPP moves inside a quad (4 consecutive lanes = the lanes of one particle): value of lane (l ^ 1), (l ^ 2)
 __device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }  // quad_perm [1,0,3,2]
@@ -120,9 +121,9 @@ __device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_update
 // 30-bin histogram (LDS atomics), every lane derives the same r_thr, pass 1 assigns slots in traversal order with a ballot
 // prefix (lane order == candidate order inside a chunk) and stops at 32. Candidates come from the staged LDS copy where the
 // cell is staged (the usual case: a list overflowed) and from global memory otherwise (wrapped / aliased / dropped cells).
-__device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, int id, int wave, int lane) {
-  const float4 me = d.sortedPos[id];
-  const int myCell = (int)d.keys[id];
+__device__ __forceinline__ void fn_exact_walk(const FnParams& d, const FnArrays& g, FnShared& sh, int id, int wave, int lane) {
+  const float4 me = g.sortedPos[id];
+  const int myCell = (int)g.keys[id];
   int lo[8], hi[8], ldsBase[8];  // sorted-index range of each cell; first LDS slot or -1 if the cell is not staged
   {
     const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
@@ -142,8 +143,8 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, i
       int c = wrap_cell(raw, d.G);
       const int r = (c == raw) ? rows[k] : -1;  // wrapped cells are never staged
       c = min(max(c, 0), d.G - 1);              // no-op for particles inside the box; keeps the table read in range
-      lo[k] = (int)d.cellStart[c];
-      hi[k] = (int)d.cellStart[c + 1];
+      lo[k] = (int)g.cellStart[c];
+      hi[k] = (int)g.cellStart[c + 1];
       ldsBase[k] = -1;
 #ifndef FN_EXACT_GLOBAL
       if (r >= 0 && hi[k] > lo[k] && lo[k] >= sh.rowLo[r] && hi[k] <= sh.rowHi[r]) ldsBase[k] = sh.rowBase[r] + (lo[k] - sh.rowLo[r]);
@@ -160,7 +161,7 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, i
       if (j < hi[k] && j != id) {
         float ox, oy, oz;
         if (ldsBase[k] >= 0) { const int sl = ldsBase[k] + (j - lo[k]); ox = sh.x[sl]; oy = sh.y[sl]; oz = sh.z[sl]; }
-        else { const float4 o = d.sortedPos[j]; ox = o.x; oy = o.y; oz = o.z; }
+        else { const float4 o = g.sortedPos[j]; ox = o.x; oy = o.y; oz = o.z; }
         const float ex = me.x - ox, ey = me.y - oy, ez = me.z - oz;
         const float d2 = ex * ex + ey * ey + ez * ez;
         if (d2 <= h2) {
@@ -190,7 +191,7 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, i
       if (j < hi[k] && j != id) {
         float ox, oy, oz;
         if (ldsBase[k] >= 0) { const int sl = ldsBase[k] + (j - lo[k]); ox = sh.x[sl]; oy = sh.y[sl]; oz = sh.z[sl]; }
-        else { const float4 o = d.sortedPos[j]; ox = o.x; oy = o.y; oz = o.z; }
+        else { const float4 o = g.sortedPos[j]; ox = o.x; oy = o.y; oz = o.z; }
         const float ex = me.x - ox, ey = me.y - oy, ez = me.z - oz;
         d2 = ex * ex + ey * ey + ez * ez;
         hit = d2 <= r2;
@@ -199,16 +200,16 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, i
       const int pos = found + __popcll(m & ltMask);
       if (hit && pos < SPH_MAXN) {
         const size_t idx = nbr_index(id, pos);
-        d.nbrId[idx] = j;
-        d.nbrDist[idx] = sqrtf(d2) * d.simScale;
+        g.nbrId[idx] = j;
+        g.nbrDist[idx] = sqrtf(d2) * d.simScale;
       }
       found += __popcll(m);
     }
   }
   if (lane >= min(found, SPH_MAXN) && lane < SPH_MAXN) {
     const size_t idx = nbr_index(id, lane);
-    d.nbrId[idx] = -1;
-    d.nbrDist[idx] = -1.f;
+    g.nbrId[idx] = -1;
+    g.nbrDist[idx] = -1.f;
   }
 }
 
@@ -218,17 +219,29 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, FnShared& sh, i
 //   A0.0 A0.1 | B1.0 B1.1 B2.0 B2.1 B3.0 B3.1 B4.0 B4.1 | A5.0 A5.1 A6.0 A6.1 A7.0 A7.1
 // and four per-piece hit counts per lane (one packed word, two DPP moves) place every neighbour in the reference's slot.
 // Pair A gets 54 % of the hits (own cell ~42 %, edges 5 % each, corner 2 %), pair B 46 % (faces ~14 % each, one edge).
-__global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
+//
+// Synchronisation: ONE workgroup barrier per batch, between the staging of the candidates and their use. Everything before it
+// (batch bounds, the 9 candidate runs, their LDS layout) is computed redundantly by every wave from loads with workgroup-uniform
+// addresses, everything after it is private to a wave (its lists, its d^2 staging area, the exact walks of its own particles).
+__global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, const float4* __restrict__ sortedPos,
+                                                                   const uint32_t* __restrict__ keys,
+                                                                   const uint32_t* __restrict__ cellStart,
+                                                                   const float* __restrict__ binU, int32_t* __restrict__ nbrId,
+                                                                   float* __restrict__ nbrDist, uint32_t* __restrict__ dbg,
+                                                                   uint32_t* __restrict__ trace) {  // trace: FN_STAMPS builds only
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = tid >> 2, quadLane = tid & 3, pairB = quadLane >> 1, sub = quadLane & 1;
-  const int rangeBegin = (int)d.cellStart[d.rangeLo], rangeEnd = (int)d.cellStart[d.rangeHi];  // all particles, or fewer ghost layers
+  const int rangeBegin = (int)cellStart[d.rangeLo], rangeEnd = (int)cellStart[d.rangeHi];  // all particles, or fewer ghost layers
   const int p0 = rangeBegin + blockIdx.x * FN_PART;
   if (p0 >= rangeEnd) return;  // uniform
   const int id = p0 + p;
   const bool alive = id < rangeEnd;
+  FnArrays g;
+  g.sortedPos = sortedPos; g.keys = keys; g.cellStart = cellStart; g.nbrId = nbrId; g.nbrDist = nbrDist;
 #ifdef FN_STAMPS
+  const unsigned long long wgStart_ = __builtin_amdgcn_s_memrealtime();  // 100 MHz
   if (tid < 16) sh.stamps[tid] = 0u;
   __syncthreads();
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
@@ -241,104 +254,72 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   // batches instead: at most 32 particles, never across an x-row boundary.
   const int blockHi = min(p0 + FN_PART, rangeEnd);
   // own record and cell: issued now, needed only after the staging
-  const float4 myPos = alive ? d.sortedPos[id] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int myCell = alive ? (int)d.keys[id] : 0;
-  if (tid == 0) { sh.batchLo = p0; sh.retry = 0; }
-  while (true) {
-  __syncthreads();  // (also protects the LDS of the previous batch, including its exact walks)
-  const int batchLo = sh.batchLo;
-  if (batchLo >= blockHi) break;  // uniform
-  if (tid < 64) {
-    int len = blockHi - batchLo;
-    if (sh.retry) {
-      const int i = batchLo + tid;
-      const unsigned row0 = d.keys[batchLo] / (unsigned)d.gx;
-      const bool stop = (tid >= 32) || (i >= blockHi) || (d.keys[min(i, blockHi - 1)] / (unsigned)d.gx != row0);
-      len = __ffsll((long long)__ballot(stop)) - 1;  // first lane that must not join the batch (lane 32 at the latest)
-    }
-    if (tid == 0) { sh.batchHi = batchLo + len; sh.nSlow = 0; }
+  const float4 myPos = alive ? sortedPos[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int myCell = alive ? (int)keys[id] : 0;
+  int batchLo = p0, retry = 0;  // uniform. retry 1: batches end at x-row boundaries; retry 2: and hold at most 32 particles
+  while (batchLo < blockHi) {
+  int batchHi = blockHi;
+  if (retry) {  // every wave finds the end of the batch itself (same data, same answer)
+    const unsigned row0 = keys[batchLo] / (unsigned)d.gx;
+    const int i0 = batchLo + lane, i1 = batchLo + 64 + lane;  // the workgroup's <= 128 particles, two per lane
+    const bool stop0 = (i0 >= blockHi) || (keys[min(i0, blockHi - 1)] / (unsigned)d.gx != row0) || (retry == 2 && lane >= 32);
+    const bool stop1 = (i1 >= blockHi) || (keys[min(i1, blockHi - 1)] / (unsigned)d.gx != row0) || (retry == 2);
+    const unsigned long long m0 = __ballot(stop0), m1 = __ballot(stop1);
+    batchHi = batchLo + (m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128));  // first particle that must not join
+    batchHi = min(batchHi, blockHi);
   }
-  __syncthreads();
-  FN_STAMP(0)
-  const int batchHi = sh.batchHi;
-  // Every global round trip below is on the workgroup's critical path, so the staging is three trips deep: (1) the batch's
-  // first / last cell, (2) the cell table of the 9 rows into LDS, (3) all candidate records at once, flat over the
-  // concatenated runs. The other workgroup of the CU covers for it meanwhile.
-  const int cLo = (int)d.keys[batchLo], cHi = (int)d.keys[batchHi - 1];
+  // The dependent global round trips below are on the workgroup's critical path: (1) the batch's first / last cell, (2) the
+  // two ends of the 9 runs, (3) all candidate records at once, flat over the concatenated runs, together with the cell-table
+  // window the particles will look their cells up in. (1) and (2) have uniform addresses.
+  const int cLo = (int)keys[batchLo], cHi = (int)keys[batchHi - 1];
   const int nc = cHi - cLo + 3;  // cells per row: cLo-1 .. cHi+1; the window holds nc+1 table entries
   const bool winOk = nc + 1 <= FN_WIN;
-  if (tid < 9 * FN_WIN) {
-    const int r = tid / FN_WIN, i = tid % FN_WIN;
-    const int sy = r % 3 - 1, sz = r / 3 - 1;
-    const int shift = sy * d.gx + sz * d.gx * d.gy;
-    if (winOk) {
-      if (i <= nc) sh.win[r][i] = (int)d.cellStart[min(max(cLo - 1 + shift + i, 0), d.G)];
-    } else if (i < 2) {  // sparse cells: only the two ends of the run (the per-particle setup reads the table directly)
-      const int a = max(cLo - 1 + shift, 0), b = min(cHi + 1 + shift, d.G - 1);
-      sh.win[r][i] = (a <= b) ? (int)d.cellStart[i == 0 ? a : b + 1] : 0;
-    }
-  }
-  if (tid >= 192 && tid < 256) sh.binU[tid - 192] = d.binU[tid - 192];
-  __syncthreads();
-  FN_STAMP(1)
-  if (tid < 64) {
-    // run table by the first 9 lanes: the own row (4) first, then the others — if LDS still runs out, the most-used runs
-    // are the ones that are staged. Lane q handles run order[q]; its base is the sum of the earlier runs' lengths.
-    const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
-    int r = 0, lo = 0, n = 0;
-    if (tid < 9) {
-      r = order[tid];
-      lo = sh.win[r][0];
-      const int hi = winOk ? sh.win[r][nc] : sh.win[r][1];
-      n = max(hi, lo) - lo;  // (clamped table reads: an out-of-grid run is empty)
-    }
-    int incl = n;  // inclusive prefix sum over lanes 0..8 (DPP row shifts; lanes >= 9 hold 0)
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
-    const int total = __shfl(incl, 8);
-    const bool tooBig = total > FN_CAND_CAP;
-    if (tooBig && !sh.retry) {
-      if (tid == 0) sh.retry = 2;  // 2 = "switch now": redo this workgroup in small batches
-    } else if (!tooBig) {
-      if (tid < 9) {
-        const int base = incl - n;
-        sh.rowLo[r] = lo; sh.rowHi[r] = lo + n; sh.rowBase[r] = base;
-        sh.segDelta[tid] = lo - base;
-        sh.segEnd[tid] = incl;
-      }
-      if (tid == 0) { sh.total = total; sh.winOk = winOk ? 1 : 0; }
-    } else if (tid == 0) {  // small batch that still does not fit (very dense cells): drop runs, serially (rare)
-      int base = 0;
-      for (int q = 0; q < 9; q++) {
-        const int rr = order[q];
-        const int l = sh.win[rr][0], hh = winOk ? sh.win[rr][nc] : sh.win[rr][1];
-        int nn = max(hh, l) - l;
-        sh.rowLo[rr] = l; sh.rowBase[rr] = base;
-        if (base + nn > FN_CAND_CAP) { nn = 0; atomicAdd(&d.dbg[3], 1u); }  // not staged
-        sh.rowHi[rr] = l + nn;
-        sh.segDelta[q] = l - base;
-        base += nn;
-        sh.segEnd[q] = base;
-      }
-      sh.total = base; sh.winOk = winOk ? 1 : 0;
-    }
-  }
-  __syncthreads();
-  FN_STAMP(2)
-  if (sh.retry == 2) {  // uniform
-    __syncthreads();
-    if (tid == 0) sh.retry = 1;
-    continue;
-  }
+  // run table: the own row (4) first, then the others — if LDS still runs out, the most-used runs are the ones that are staged
+  constexpr int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+  int runLo[9], runN[9], total = 0;
   {
-    const int total = sh.total;
-    int se[8], sd[9];
+    // the 18 run ends in ONE round trip: lane 2q + e loads end e of run q, the values are then broadcast with v_readlane
+    const int q = min(lane >> 1, 8);
+    const int r = (int)((0x862071534ull >> (4 * q)) & 15ull);  // order[q]
+    const int shift = (r % 3 - 1) * d.gx + (r / 3 - 1) * d.gx * d.gy;
+    const int cell = ((lane & 1) ? cHi + 2 : cLo - 1) + shift;
+    const int v = (int)cellStart[min(max(cell, 0), d.G)];  // (clamped table reads: an out-of-grid run is empty)
 #pragma unroll
-    for (int q = 0; q < 8; q++) se[q] = sh.segEnd[q];
+    for (int qq = 0; qq < 9; qq++) {
+      const int lo = __builtin_amdgcn_readlane(v, 2 * qq), hi = __builtin_amdgcn_readlane(v, 2 * qq + 1);
+      runLo[qq] = lo; runN[qq] = max(hi - lo, 0);
+      total += runN[qq];
+    }
+  }
+  if (total > FN_CAND_CAP) {
+    // redo in smaller batches (nothing was written to LDS yet): first one batch per x-row of cells — a workgroup that straddles two
+    // rows has runs that span whole rows —, then batches of at most 32 particles (very dense cells)
+    if (retry < 2) { retry++; continue; }
+    total = 0;  // a small batch that still does not fit (very dense cells): drop runs (rare; their particles take the exact walk)
 #pragma unroll
-    for (int q = 0; q < 9; q++) sd[q] = sh.segDelta[q];
+    for (int q = 0; q < 9; q++) {
+      if (total + runN[q] > FN_CAND_CAP) { runN[q] = 0; if (tid == 0) atomicAdd(&dbg[3], 1u); }
+      total += runN[q];
+    }
+  }
+  int se[9], sd[9];  // flat staging: LDS slots < se[q] belong to run q; sorted index = slot + sd[q]
+  {
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) { sd[q] = runLo[q] - base; base += runN[q]; se[q] = base; }
+  }
+  if (tid == 0) {  // the tables the per-particle setup and the exact walk index by row
+#pragma unroll
+    for (int q = 0; q < 9; q++) { sh.rowLo[order[q]] = runLo[q]; sh.rowHi[order[q]] = runLo[q] + runN[q]; sh.rowBase[order[q]] = se[q] - runN[q]; }
+  }
+  if (winOk && tid < 9 * FN_WIN) {
+    const int r = tid / FN_WIN, i = tid % FN_WIN;
+    const int shift = (r % 3 - 1) * d.gx + (r / 3 - 1) * d.gx * d.gy;
+    if (i <= nc) sh.win[r][i] = (int)cellStart[min(max(cLo - 1 + shift + i, 0), d.G)];
+  }
+  if (tid >= 192 && tid < 256) sh.binU[tid - 192] = binU[tid - 192];
+  FN_STAMP(0)
+  {
     constexpr int PER = 6;  // records per thread and round, all loads of a round in flight together (3072 per round)
 #pragma unroll 1
     for (int f0 = 0; f0 < total; f0 += PER * FN_THREADS) {
@@ -349,7 +330,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
         int delta = sd[0];
 #pragma unroll
         for (int q = 0; q < 8; q++) delta = (f >= se[q]) ? sd[q + 1] : delta;  // runs are laid out in order of q
-        if (f < total) rec[u] = d.sortedPos[f + delta];
+        if (f < total) rec[u] = sortedPos[f + delta];
       }
 #pragma unroll
       for (int u = 0; u < PER; u++) {
@@ -360,8 +341,8 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   }
   __syncthreads();
   FN_STAMP(3)
-  if (tid == 0) sh.batchLo = batchHi;  // next batch (every thread has read batchLo / batchHi by now)
   const bool mine_now = alive && id >= batchLo && id < batchHi;  // this lane's particle belongs to the current batch
+  bool slow = false;
 
   if (mine_now) {  // (whole quads: the four lanes of a particle agree)
   // (opaque to the optimiser: everything derived from the particle's record is otherwise hoisted out of the batch loop,
@@ -369,7 +350,6 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   float4 me = myPos;
   int myCellNow = myCell, idNow = id;
   asm volatile("" : "+v"(me.x), "+v"(me.y), "+v"(me.z), "+v"(myCellNow), "+v"(idNow));
-  bool slow = false;
   int pLo[4], pHi[4], absDelta[4];  // this lane's four pieces as LDS slot ranges; sorted index = LDS slot + absDelta
   int selfSlot = -1;
   {  // the lane's four cells (sphFluid.cl:253-308) with the cell table read from the LDS window where possible
@@ -382,7 +362,6 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
     const int dz = ((pz - cfz) < d.h) ? -1 : 1;
     const int sy = dy * d.gx, sz = dz * d.gx * d.gy;
     const int ry = dy + 1, rz = dz + 1;  // staged-row ids: row = (y step + 1) + 3 * (z step + 1)
-    const bool useWin = sh.winOk != 0;
     // pair A: cells 0 (own), 5 (xz), 6 (yz), 7 (xyz); pair B: cells 1 (x), 2 (y), 3 (z), 4 (xy)
     const bool stepX[4] = {pairB != 0, pairB == 0, false, true};
     const bool stepY[4] = {false, pairB != 0, pairB == 0, true};
@@ -394,15 +373,15 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
       const int row = (stepY[i] ? ry : 1) + 3 * (stepZ[i] ? rz : 1);
       const int c = wrap_cell(raw, d.G);
       int lo, hi;
-      bool staged = c == raw;  // wrapped cells are never staged: only their emptiness matters
-      if (staged && useWin) {
+      const bool staged = c == raw;  // wrapped cells are never staged: only their emptiness matters
+      if (staged && winOk) {
         const int w = myCellNow - cLo + 1 + xs;  // in [0, nc): the batch's cells are cLo..cHi, the window starts at cLo-1
         lo = sh.win[row][w];
         hi = sh.win[row][w + 1];
       } else {  // wrapped cells and batches wider than the window
         const int cc = min(max(c, 0), d.G - 1);
-        lo = (int)d.cellStart[cc];
-        hi = (int)d.cellStart[cc + 1];
+        lo = (int)cellStart[cc];
+        hi = (int)cellStart[cc + 1];
       }
       const int n = hi - lo;
       int base = 0;
@@ -426,7 +405,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   if (slow) {
 #pragma unroll
     for (int i = 0; i < 4; i++) pHi[i] = pLo[i];
-    if (quadLane == 0) atomicAdd(&d.dbg[0], 1u);
+    if (quadLane == 0) atomicAdd(&dbg[0], 1u);
   }
   FN_STAMP(4)
 
@@ -443,10 +422,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   // of a piece, the few set bits are turned into list entries in traversal order.
   const float r2f = sh.binU[63];  // max(h, 31h/30)^2 * (1 + 2^-20), computed on the host
   const f32x2 thr = {r2f, r2f};
-#define FN_LOAD(a, X, Y, Z)                                                                     \
-  const f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);                                    \
-  const f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);                                    \
-  const f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
+  uint16_t (*const myList)[64] = sh.list[wave];
 #define FN_TEST(X, Y, Z)                                                                        \
   {                                                                                             \
     const f32x2 ex0 = mx - X.xy, ex1 = mx - X.zw, ey0 = my - Y.xy, ey1 = my - Y.zw;             \
@@ -472,7 +448,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
     }                                                                                           \
     while (m != 0u) {                                                                           \
       const int bpos = __clz((int)m);                                                           \
-      sh.list[min(cnt, FN_LIST_CAP - 1)][tid] = (uint16_t)(aBase + bpos);                       \
+      myList[min(cnt, FN_LIST_CAP - 1)][lane] = (uint16_t)(aBase + bpos);                       \
       cnt++;                                                                                    \
       m &= ~(0x80000000u >> bpos);                                                              \
     }                                                                                           \
@@ -487,15 +463,23 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
       f32x4 X = *reinterpret_cast<const f32x4*>(&sh.x[a]);
       f32x4 Y = *reinterpret_cast<const f32x4*>(&sh.y[a]);
       f32x4 Z = *reinterpret_cast<const f32x4*>(&sh.z[a]);
+      f32x4 Xb = *reinterpret_cast<const f32x4*>(&sh.x[a + 4]);
+      f32x4 Yb = *reinterpret_cast<const f32x4*>(&sh.y[a + 4]);
+      f32x4 Zb = *reinterpret_cast<const f32x4*>(&sh.z[a + 4]);
       while (a < pieceHi) {
-        // two quads per trip, ping-pong: the next quad's three LDS reads are issued before the current quad is tested.
-        // Reads and tests may run up to 11 slots past the piece (FN_CAND_PAD); FN_FLUSH masks those bits.
-        FN_LOAD(a + 4, Xb, Yb, Zb)
+        // two quads per trip; each quad's three LDS reads are issued a whole trip before it is tested (its registers are
+        // refilled right after their last use). Reads and tests may run up to 15 slots past the piece (FN_CAND_PAD);
+        // FN_FLUSH masks those bits.
         FN_TEST(X, Y, Z)
         X = *reinterpret_cast<const f32x4*>(&sh.x[a + 8]);
         Y = *reinterpret_cast<const f32x4*>(&sh.y[a + 8]);
         Z = *reinterpret_cast<const f32x4*>(&sh.z[a + 8]);
+        __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from sinking the reads to the end of the trip, next to their use)
         FN_TEST(Xb, Yb, Zb)
+        Xb = *reinterpret_cast<const f32x4*>(&sh.x[a + 12]);
+        Yb = *reinterpret_cast<const f32x4*>(&sh.y[a + 12]);
+        Zb = *reinterpret_cast<const f32x4*>(&sh.z[a + 12]);
+        __builtin_amdgcn_sched_barrier(0);
         a += 8; k += 8;
         if (k == 32) { FN_FLUSH(32) aBase = a; k = 0; }
       }
@@ -503,7 +487,6 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
     }
     segEnd[i] = cnt;
   }
-#undef FN_LOAD
 #undef FN_TEST
 #undef FN_FLUSH
   FN_STAMP(5)
@@ -511,22 +494,24 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   over |= quad_xor1(over);  // all four lanes of the quad take part
   over |= quad_xor2(over);
   if (over) {
-    if (quadLane == 0 && !slow) atomicAdd(&d.dbg[1], 1u);
+    if (quadLane == 0 && !slow) atomicAdd(&dbg[1], 1u);
     slow = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) segEnd[i] = 0;
   }
 
   // ---- 2. replay of the reference's two passes over the short lists, entirely in registers: the list (<= 24 LDS slots
-  // per lane) is expanded once into d2v[] with static indices, 8 entries at a time with a wave-uniform skip.
+  // per lane) is expanded once into d2v[] with static indices, 8 entries at a time with a wave-uniform skip. The slots are
+  // kept (two per register): the list area is about to be reused.
   const int total = segEnd[3];
   float d2v[FN_LIST_CAP];
+  uint32_t slotPk[FN_LIST_CAP / 2];
 #pragma unroll
   for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
     if (__any(c0 < total)) {
       int slotv[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) slotv[u] = min((int)sh.list[c0 + u][tid], FN_CAND_CAP + FN_CAND_PAD - 1);
+      for (int u = 0; u < 8; u++) slotv[u] = min((int)myList[c0 + u][lane], FN_CAND_CAP + FN_CAND_PAD - 1);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int sl = slotv[u];
@@ -534,9 +519,13 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
         const float v = ex * ex + ey * ey + ez * ez;
         d2v[c0 + u] = (c0 + u < total) ? v : __builtin_inff();  // +inf never passes a `<` / `<=` test below
       }
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) slotPk[(c0 + u) >> 1] = (uint32_t)slotv[u] | ((uint32_t)slotv[u + 1] << 16);
     } else {
 #pragma unroll
       for (int u = 0; u < 8; u++) d2v[c0 + u] = __builtin_inff();
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) slotPk[(c0 + u) >> 1] = 0u;
     }
   }
   FN_STAMP(6)
@@ -591,11 +580,12 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
   const int partner = quad_xor1(packed);        // the other half of the same four cells
   const int cellTot = packed + partner;         // whole-cell counts of this pair (bytes <= 48: no carry)
   const int otherTot = quad_xor2(cellTot);      // whole-cell counts of the other pair
+  // (the wave's list area is free from here on: every lane has its slots in slotPk, and LDS operations of a wave retire in order)
   if (!slow) {
     const int c0b = cellTot & 255, c1b = (cellTot >> 8) & 255, c2b = (cellTot >> 16) & 255, c3b = (cellTot >> 24) & 255;
     const int o0b = otherTot & 255;
     const int sumOther = o0b + ((otherTot >> 8) & 255) + ((otherTot >> 16) & 255) + ((otherTot >> 24) & 255);
-    const int run = c0b + c1b + c2b + c3b + sumOther;
+    const int run = min(c0b + c1b + c2b + c3b + sumOther, SPH_MAXN);
     // pair A (cells 0 | 5 6 7): cell 0 starts at 0, cells 5.. after cell 0 and all of pair B;
     // pair B (cells 1 2 3 4): starts after cell 0 (= pair A's first cell)
     const int first = pairB ? o0b : 0, afterFirst = pairB ? 0 : sumOther;
@@ -604,11 +594,15 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
     start[1] = first + c0b + afterFirst + (sub ? ((partner >> 8) & 255) : 0);
     start[2] = first + c0b + afterFirst + c1b + (sub ? ((partner >> 16) & 255) : 0);
     start[3] = first + c0b + afterFirst + c1b + c2b + (sub ? ((partner >> 24) & 255) : 0);
+    // Ids go straight to the tiled map (4-byte stores); the d^2 of the accepted neighbours go to the wave's staging area
+    // [particle][slot], from which every lane of the quad then takes 8 consecutive slots: 8 square roots per lane instead of
+    // one per list entry, and the distances leave as two 16-byte stores per lane (which also write the -1 of the unused slots).
+    int tidNow = tid;  // (opaque: keeps the address below from being hoisted to the kernel's prologue and spilled)
+    asm volatile("" : "+v"(tidNow));
+    float* const dstRow = reinterpret_cast<float*>(&sh.list[0][0][0]) + (tidNow >> 6) * (FN_LIST_CAP * 64 / 2) + ((tidNow & 63) >> 2) * FN_DST_STRIDE;
+    const uint32_t mapBase = ((uint32_t)(idNow >> 6) * (8u * 64u) + (uint32_t)(idNow & 63)) << 2;  // element index of slot 0 (< 2^32: N <= 2^27)
     // walk the entries in list order with a running (piece start, index delta, rank inside the piece)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
-    const size_t mapBase = ((size_t)(idNow >> 6) * 8 * 64 + (size_t)(idNow & 63)) << 2;
-    int32_t* const idBase = d.nbrId + mapBase;
-    float* const distBase = d.nbrDist + mapBase;
 #pragma unroll
     for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
       if (!__any(c0 < total)) continue;  // wave-uniform skip of empty chunks
@@ -622,35 +616,47 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d) {
           const int pos = curStart + rank;
           rank++;
           if (pos < SPH_MAXN) {
-            const int off = ((pos >> 2) << 8) + (pos & 3);  // tiled map: group stride 64 lanes * 4 slots
-            idBase[off] = (int)sh.list[e][tid] + curDelta;
-            distBase[off] = sqrtf(d2v[e]) * d.simScale;
+            nbrId[mapBase + (uint32_t)(((pos >> 2) << 8) + (pos & 3))] = (int)((slotPk[e >> 1] >> ((e & 1) * 16)) & 0xffffu) + curDelta;  // tiled map: group stride 64 lanes * 4 slots
+            dstRow[pos] = d2v[e];
           }
         }
       }
     }
-    for (int k = min(run, SPH_MAXN) + quadLane; k < SPH_MAXN; k += FN_LANES) {  // K1 folded in: unused slots = (-1, -1)
-      const size_t idx = nbr_index(idNow, k);
-      d.nbrId[idx] = -1;
-      d.nbrDist[idx] = -1.f;
-    }
+    for (int k = run + quadLane; k < SPH_MAXN; k += FN_LANES) nbrId[mapBase + (uint32_t)(((k >> 2) << 8) + (k & 3))] = -1;  // K1 folded in: unused id slots
+    const f32x4 da = *reinterpret_cast<const f32x4*>(dstRow + 8 * quadLane), db = *reinterpret_cast<const f32x4*>(dstRow + 8 * quadLane + 4);
+    const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+    float out[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j] = (8 * quadLane + j < run) ? sqrtf(dv[j]) * d.simScale : -1.f;
+    float* const distBase = nbrDist + (size_t)(mapBase + (uint32_t)(2 * quadLane) * 256u);
+    *reinterpret_cast<f32x4*>(distBase) = f32x4{out[0], out[1], out[2], out[3]};
+    *reinterpret_cast<f32x4*>(distBase + 256) = f32x4{out[4], out[5], out[6], out[7]};
   }
-  // ---- the rare particles the fast path cannot serve are left to the exact wave-per-particle walk below
-  if (slow && quadLane == 0) sh.slowList[atomicAdd(&sh.nSlow, 1)] = idNow;
   FN_STAMP(8)
   }  // mine_now
 
-  __syncthreads();
+  // ---- the rare particles the fast path cannot serve: the exact walk, by the wave that owns them (uniform control flow)
   {
-    const int nSlow = sh.nSlow;  // uniform
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int s = wave; s < nSlow; s += FN_WAVES) fn_exact_walk(d, sh, sh.slowList[s], wave, lane);
+    unsigned long long todo = __ballot(mine_now && slow && quadLane == 0);
+    while (todo != 0ull) {
+      const int b = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      fn_exact_walk(d, g, sh, p0 + wave * 16 + (b >> 2), wave, lane);
+    }
   }
   FN_STAMP(9)
+  batchLo = batchHi;
+  if (batchLo < blockHi) __syncthreads();  // (uniform) the next batch overwrites the staging area
   }  // batches
 #ifdef FN_STAMPS
   __syncthreads();
-  if (tid < 16) atomicAdd(&d.dbg[16 + tid], sh.stamps[tid] >> 6);
+  if (tid < 16) atomicAdd(&dbg[16 + tid], sh.stamps[tid] >> 6);
+  if (tid == 0) {  // residency trace: when and where this workgroup ran
+    trace[4 * blockIdx.x + 0] = (uint32_t)wgStart_;
+    trace[4 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+  }
 #endif
 }
 
@@ -670,9 +676,9 @@ int sphk_find_neighbors(sph_solver* s, int ghostDepth) {
   a.G = r.G; a.gx = r.gx; a.gy = r.gy; a.rangeLo = r.rangeLo; a.rangeHi = r.rangeHi;
   a.h = r.h; a.cellSize = r.cellSize; a.cellSizeInv = r.cellSizeInv; a.simScale = r.simScale;
   a.xmin = r.xmin; a.ymin = r.ymin; a.zmin = r.zmin;
-  a.sortedPos = r.sortedPos; a.keys = r.keys; a.cellStart = r.cellStart;
-  a.nbrId = r.nbrId; a.nbrDist = r.nbrDist; a.binU = r.binU; a.dbg = r.dbg;
-  hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, a);
+  hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, a,
+                     (const float4*)r.sortedPos, (const uint32_t*)r.keys, (const uint32_t*)r.cellStart, r.binU, r.nbrId, r.nbrDist, r.dbg,
+                     r.valsAlt /* idle between the sort and the next step's sort */);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }

@@ -300,7 +300,7 @@ _BUF_DTYPE = {"position": np.float32, "velocity": np.float32, "sortedPosition": 
               "sortedVelocity": np.float32, "acceleration": np.float32, "neighborMap": np.float32,
               "neighborIds": np.int32, "particleIndex": np.uint32, "particleIndexBack": np.uint32,
               "gridCellIndex": np.uint32, "gridCellIndexFixedUp": np.uint32, "pressure": np.float32,
-              "rho": np.float32, "debugCounters": np.uint32}
+              "rho": np.float32, "debugCounters": np.uint32, "diagnosticTrace": np.uint32}
 
 
 def _ptr(a):

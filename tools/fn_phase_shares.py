@@ -14,10 +14,34 @@ h._runFindNeighbors(); h.synchronize(); h.reset_stage_times()
 for _ in range(reps): h._runFindNeighbors()
 h.synchronize()
 c = h.buffer("debugCounters").astype(float)
-names = ["batch bounds", "cell-table window", "run table", "candidate loads", "setup", "walk", "expand", "bisect", "pass1+store", "exact walks+barrier"]
+names = ["head (bounds, run table)", "-", "-", "candidate loads + barrier", "setup", "walk", "expand", "bisect", "pass1+store", "exact walks"]
 tot = c[16:26].sum()
 waves = reps * ((sc["cfg"].particleCount + 127) // 128) * 8
 print("phase shares (cycles per wave in brackets):")
 for i, n in enumerate(names):
     print("  %-22s %5.1f %%  [%7.0f]" % (n, 100 * c[16 + i] / max(tot, 1), 64 * c[16 + i] / waves))
 print("  total cycles per wave %.0f" % (64 * tot / waves))
+
+# residency: how many workgroups of the LAST launch were resident per CU over time (trace written by the diagnostic build)
+import numpy as np
+nwg = (sc["cfg"].particleCount + 127) // 128
+t = h.buffer("diagnosticTrace")[:4 * nwg].reshape(-1, 4)
+start, end, hw, xcc = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2], t[:, 3] & 15
+t0 = start.min(); start -= t0; end -= t0
+cu = ((xcc.astype(np.int64) << 16) | (((hw >> 13) & 7).astype(np.int64) << 8) | (((hw >> 12) & 1).astype(np.int64) << 4) | ((hw >> 8) & 15))
+dur = (end - start)
+print("workgroups %d, kernel span %.1f us, workgroup lifetime mean %.1f us p50 %.1f max %.1f" % (nwg, end.max() / 100.0, dur.mean() / 100.0, np.median(dur) / 100.0, dur.max() / 100.0))
+ucu = np.unique(cu)
+print("distinct CUs seen:", ucu.size, " workgroups per CU: min %d max %d" % (np.bincount(np.searchsorted(ucu, cu)).min(), np.bincount(np.searchsorted(ucu, cu)).max()))
+# time-averaged residency per CU
+res = []
+for c in ucu[:64]:
+    m = cu == c
+    res.append(dur[m].sum() / float(end[m].max() - start[m].min()))
+print("time-averaged resident workgroups per CU (first 64 CUs): mean %.2f min %.2f max %.2f" % (np.mean(res), np.min(res), np.max(res)))
+import os
+out = os.path.join(ROOT, "gpurun_out", "fn_trace.npz")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+pi = h.buffer("particleIndex").reshape(-1, 2)
+np.savez_compressed(out, trace=t, cells=pi[:, 0], gx=sc["cfg"].gridCellsX)
+print("trace saved to", out)

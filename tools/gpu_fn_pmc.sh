@@ -11,7 +11,11 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
   --output-format csv -d $OUT/pmcA -- python3 tools/time_find_neighbors.py 5 > $OUT/pmcA.log 2>&1 || { tail -20 $OUT/pmcA.log; exit 1; }
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD \
   --output-format csv -d $OUT/pmcB -- python3 tools/time_find_neighbors.py 5 > $OUT/pmcB.log 2>&1 || { tail -20 $OUT/pmcB.log; exit 1; }
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_LEVEL_WAVES \
+  --output-format csv -d $OUT/pmcC -- python3 tools/time_find_neighbors.py 5 > $OUT/pmcC.log 2>&1 || { tail -20 $OUT/pmcC.log; }
+python tools/pmc_table.py $OUT/pmcC/*/*counter_collection.csv > $OUT/pmc_SQ_C.txt
 python tools/pmc_table.py $OUT/pmcA/*/*counter_collection.csv > $OUT/pmc_SQ_A.txt
 python tools/pmc_table.py $OUT/pmcB/*/*counter_collection.csv > $OUT/pmc_SQ_B.txt
-grep -E "kernel|find_neighbors" $OUT/pmc_SQ_A.txt $OUT/pmc_SQ_B.txt
-rm -rf $OUT/pmcA $OUT/pmcB
+grep -E "kernel|find_neighbors" $OUT/pmc_SQ_A.txt $OUT/pmc_SQ_B.txt $OUT/pmc_SQ_C.txt
+grep -h find_neighbors $OUT/pmcA/*/*kernel_trace.csv | head -3
+rm -rf $OUT/pmcA $OUT/pmcB $OUT/pmcC
