@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "sph_common.h"
 
@@ -68,8 +69,12 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
 }
 
 #define FN_PART 128               // particles per workgroup
-#define FN_LANES 4                // lanes per particle (one DPP quad)
+#ifndef FN_LANES
+#define FN_LANES 2                // lanes per particle: 2 (a pair; whole cells) or 4 (a DPP quad: pairs x cell halves). A/B on MI355X,
+#endif                            // config #2: 2 lanes 0.44 ms, 4 lanes 0.58 ms (more waves per SIMD, but 30 % more instructions)
+#define FN_LOG_LANES (FN_LANES == 4 ? 2 : 1)
 #define FN_THREADS (FN_LANES * FN_PART)
+#define FN_PER_WAVE (64 / FN_LANES)  // particles per wave
 #define FN_WAVES (FN_THREADS / 64)
 #ifndef FN_CAND_CAP
 #define FN_CAND_CAP 4096          // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
@@ -77,8 +82,9 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
 #define FN_WIN 16                 // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
 #define FN_CAND_PAD 16            // the aligned, prefetching 4-wide walk reads (never uses) up to 15 slots past a piece
 #ifndef FN_LIST_CAP
-#define FN_LIST_CAP 24            // compaction list entries per lane (u16 [entry][lane]); 96 per particle
+#define FN_LIST_CAP (96 / FN_LANES)  // compaction list entries per lane (u16 [entry][lane]); 96 per particle
 #endif
+#define FN_SLOTS_PER_LANE (SPH_MAXN / FN_LANES)  // map slots every lane of a particle finishes (square root + store)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -98,11 +104,18 @@ struct FnShared {
   uint32_t stamps[16];                            // diagnostic build: cycles per phase, summed over the workgroup's waves
 #endif
 };
-static_assert(16 * FN_DST_STRIDE * 4 <= FN_LIST_CAP * 64 * 2, "d^2 staging must fit the wave's list area");
+static_assert(FN_PER_WAVE * FN_DST_STRIDE * 4 <= FN_LIST_CAP * 64 * 2, "d^2 staging must fit the wave's list area");
+static_assert(FN_LANES == 2 || FN_LANES == 4, "two or four lanes per particle");
 
 // DPP moves inside a quad (4 consecutive lanes = the lanes of one particle): value of lane (l ^ 1), (l ^ 2)
 __device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }  // quad_perm [1,0,3,2]
 __device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }  // quad_perm [2,3,0,1]
+// the lanes of one particle: value held by the lane of the OTHER PAIR (same half) / by the lane of the other HALF (same pair; none with two lanes)
+__device__ __forceinline__ int grp_other_pair(int v) { return FN_LANES == 4 ? quad_xor2(v) : quad_xor1(v); }
+__device__ __forceinline__ int grp_other_half(int v) { return FN_LANES == 4 ? quad_xor1(v) : 0; }
+typedef typename std::conditional<(FN_LIST_CAP > 32), unsigned long long, uint32_t>::type fn_mask_t;  // one bit per list entry
+__device__ __forceinline__ int fn_popc(uint32_t v) { return __popc(v); }
+__device__ __forceinline__ int fn_popc(unsigned long long v) { return __popcll(v); }
 
 // d.dbg layout: [0] particles handed to the exact wave-per-particle walk because a cell was not staged, [1] because a list
 // overflowed, [3] candidate runs dropped for LDS capacity. With FN_STAMPS (diagnostic build only): [16..25] cycles / 64 per phase.
@@ -223,7 +236,7 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, const FnArrays&
 // Synchronisation: ONE workgroup barrier per batch, between the staging of the candidates and their use. Everything before it
 // (batch bounds, the 9 candidate runs, their LDS layout) is computed redundantly by every wave from loads with workgroup-uniform
 // addresses, everything after it is private to a wave (its lists, its d^2 staging area, the exact walks of its own particles).
-__global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, const float4* __restrict__ sortedPos,
+__global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_neighbors(FnParams d, const float4* __restrict__ sortedPos,
                                                                    const uint32_t* __restrict__ keys,
                                                                    const uint32_t* __restrict__ cellStart,
                                                                    const float* __restrict__ binU, int32_t* __restrict__ nbrId,
@@ -232,7 +245,8 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = tid >> 2, quadLane = tid & 3, pairB = quadLane >> 1, sub = quadLane & 1;
+  const int p = tid >> FN_LOG_LANES, quadLane = tid & (FN_LANES - 1);  // quadLane: lane inside the particle's group
+  const int pairB = FN_LANES == 4 ? quadLane >> 1 : quadLane, sub = FN_LANES == 4 ? (quadLane & 1) : 0;
   const int rangeBegin = (int)cellStart[d.rangeLo], rangeEnd = (int)cellStart[d.rangeHi];  // all particles, or fewer ghost layers
   const int p0 = rangeBegin + blockIdx.x * FN_PART;
   if (p0 >= rangeEnd) return;  // uniform
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
   if (tid >= 192 && tid < 256) sh.binU[tid - 192] = binU[tid - 192];
   FN_STAMP(0)
   {
-    constexpr int PER = 6;  // records per thread and round, all loads of a round in flight together (3072 per round)
+    constexpr int PER = FN_LANES == 4 ? 6 : 8;  // records per thread and round, all loads of a round in flight together
 #pragma unroll 1
     for (int f0 = 0; f0 < total; f0 += PER * FN_THREADS) {
       float4 rec[PER];
@@ -389,8 +403,9 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
         if (staged && lo >= sh.rowLo[row] && hi <= sh.rowHi[row]) base = sh.rowBase[row] + (lo - sh.rowLo[row]);
         else slow = true;  // a non-empty cell of this particle is not in LDS
       }
-      // halves: the split point is rounded to a 16-byte boundary of the SoA arrays so the second half starts aligned
-      const int mid = min(base + n, max(base, (base + (n >> 1) + 2) & ~3));
+      // halves (four lanes per particle): the split point is rounded to a 16-byte boundary of the SoA arrays so the second
+      // half starts aligned; with two lanes per particle a lane walks whole cells
+      const int mid = FN_LANES == 4 ? min(base + n, max(base, (base + (n >> 1) + 2) & ~3)) : base + n;
       pLo[i] = sub ? mid : base;
       pHi[i] = sub ? base + n : mid;
       absDelta[i] = lo - base;
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
   }
   {  // both pairs must agree (inside a pair the lanes see the same cells). The DPP move is executed by ALL four lanes — under a
      // short-circuit `||` the lanes that are already slow would sit it out and their partners would read 0 from them.
-    const int otherPair = quad_xor2((int)slow);
+    const int otherPair = grp_other_pair((int)slow);
     slow = slow || (otherPair != 0);
   }
   if (slow) {
@@ -416,20 +431,20 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
   int segEnd[4];
   const f32x2 mx = {me.x, me.x}, my = {me.y, me.y}, mz = {me.z, me.z};
   // The filter only has to be a superset of both reference passes (the replay below decides with the reference's exact
-  // expressions), so it may use fused multiply-adds: its d^2 differs from the reference's by < 2^-21 relative, which the
-  // 2^-20 margin on the radius absorbs. A hit is the SIGN BIT of d^2 - r^2 (two distinct floats never subtract to zero with
-  // denormals on), shifted into a per-lane bit mask with one v_alignbit per candidate; every 32 candidates, and at the end
-  // of a piece, the few set bits are turned into list entries in traversal order.
+  // expressions), so it evaluates d^2 - R^2 as one chain of fused multiply-adds starting at -R^2, R^2 = r_max^2 (1 + 2^-20): the
+  // chain differs from the reference's separately rounded d^2 by < 2^-21 R^2 (three roundings of <= 2^-24 max(d^2, R^2) each, plus
+  // the reference's own three), so every candidate with d^2 <= r_max^2 comes out strictly negative. A hit is the SIGN BIT of that
+  // value, shifted into a per-lane bit mask with one v_alignbit per candidate; every 32 candidates, and at the end of a piece,
+  // the few set bits are turned into list entries in traversal order.
   const float r2f = sh.binU[63];  // max(h, 31h/30)^2 * (1 + 2^-20), computed on the host
-  const f32x2 thr = {r2f, r2f};
+  const f32x2 nthr = {-r2f, -r2f};
   uint16_t (*const myList)[64] = sh.list[wave];
 #define FN_TEST(X, Y, Z)                                                                        \
   {                                                                                             \
     const f32x2 ex0 = mx - X.xy, ex1 = mx - X.zw, ey0 = my - Y.xy, ey1 = my - Y.zw;             \
     const f32x2 ez0 = mz - Z.xy, ez1 = mz - Z.zw;                                               \
-    const f32x2 q0 = __builtin_elementwise_fma(ez0, ez0, __builtin_elementwise_fma(ey0, ey0, ex0 * ex0)); \
-    const f32x2 q1 = __builtin_elementwise_fma(ez1, ez1, __builtin_elementwise_fma(ey1, ey1, ex1 * ex1)); \
-    const f32x2 s0 = q0 - thr, s1 = q1 - thr;                                                   \
+    const f32x2 s0 = __builtin_elementwise_fma(ez0, ez0, __builtin_elementwise_fma(ey0, ey0, __builtin_elementwise_fma(ex0, ex0, nthr))); \
+    const f32x2 s1 = __builtin_elementwise_fma(ez1, ez1, __builtin_elementwise_fma(ey1, ey1, __builtin_elementwise_fma(ex1, ex1, nthr))); \
     acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s0.x), 31);                            \
     acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s0.y), 31);                            \
     acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s1.x), 31);                            \
@@ -446,13 +461,16 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
       const unsigned ts = (unsigned)(selfSlot - aBase);                                         \
       if (ts < 32u) m &= ~(0x80000000u >> ts);                                                  \
     }                                                                                           \
+    cnt += __popc(m);                                                                           \
+    if (cnt > FN_LIST_CAP) m = 0u;                        /* overflow: the particle takes the exact walk, nothing more is written */ \
     while (m != 0u) {                                                                           \
       const int bpos = __clz((int)m);                                                           \
-      myList[min(cnt, FN_LIST_CAP - 1)][lane] = (uint16_t)(aBase + bpos);                       \
-      cnt++;                                                                                    \
+      *wr = (uint16_t)(aBase + bpos);                                                           \
+      wr += 64;                                           /* next entry of this lane */         \
       m &= ~(0x80000000u >> bpos);                                                              \
     }                                                                                           \
   }
+  uint16_t* wr = &myList[0][lane];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int pieceLo = pLo[i], pieceHi = pHi[i];
@@ -467,9 +485,10 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
       f32x4 Yb = *reinterpret_cast<const f32x4*>(&sh.y[a + 4]);
       f32x4 Zb = *reinterpret_cast<const f32x4*>(&sh.z[a + 4]);
       while (a < pieceHi) {
-        // two quads per trip; each quad's three LDS reads are issued a whole trip before it is tested (its registers are
+        // two quads per trip; each quad's three LDS reads are issued a whole quad test before it is used (its registers are
         // refilled right after their last use). Reads and tests may run up to 15 slots past the piece (FN_CAND_PAD);
-        // FN_FLUSH masks those bits.
+        // FN_FLUSH masks those bits. (A/B: hand-placed counted lgkmcnt waits instead of hipcc's changed nothing — the loop is
+        // bound by the issue rate of its packed-f32 arithmetic, not by LDS latency.)
         FN_TEST(X, Y, Z)
         X = *reinterpret_cast<const f32x4*>(&sh.x[a + 8]);
         Y = *reinterpret_cast<const f32x4*>(&sh.y[a + 8]);
@@ -491,8 +510,8 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
 #undef FN_FLUSH
   FN_STAMP(5)
   int over = cnt > FN_LIST_CAP ? 1 : 0;
-  over |= quad_xor1(over);  // all four lanes of the quad take part
-  over |= quad_xor2(over);
+  over |= grp_other_half(over);  // all lanes of the particle take part
+  over |= grp_other_pair(over);
   if (over) {
     if (quadLane == 0 && !slow) atomicAdd(&dbg[1], 1u);
     slow = true;
@@ -548,8 +567,8 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
         for (int u = 0; u < 8; u++) c += (d2v[c0 + u] < U) ? 1 : 0;
       }
     }
-    c += quad_xor1(c);
-    c += quad_xor2(c);
+    c += grp_other_half(c);
+    c += grp_other_pair(c);
     if (lo < hi) {
       if (c >= SPH_MAXN) { hi = mid; cAtHi = c; } else lo = mid + 1;
     }
@@ -561,25 +580,25 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
   // ---- 2b. pass 1: hits with d^2 <= r_thr^2 as a bit mask; per-piece counts by popcount, exchanged inside the quad as one
   // packed word; every hit goes to (hits in earlier pieces of the merged order) + (rank inside its piece). Slots >= 32
   // are dropped, which is what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
-  uint32_t acc = 0u;
+  fn_mask_t acc = 0;
 #pragma unroll
   for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
     if (c0 < liveEnd) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc |= (d2v[c0 + u] <= r2) ? (1u << (c0 + u)) : 0u;
+      for (int u = 0; u < 8; u++) acc |= (d2v[c0 + u] <= r2) ? ((fn_mask_t)1 << (c0 + u)) : (fn_mask_t)0;
     }
   }
-  uint32_t below[4];  // bits of the entries before the end of piece i
+  fn_mask_t below[4];  // bits of the entries before the end of piece i
 #pragma unroll
-  for (int i = 0; i < 4; i++) below[i] = (segEnd[i] >= 32) ? ~0u : ((1u << segEnd[i]) - 1u);
+  for (int i = 0; i < 4; i++) below[i] = (segEnd[i] >= (int)(8 * sizeof(fn_mask_t))) ? ~(fn_mask_t)0 : (((fn_mask_t)1 << segEnd[i]) - 1);
   int mine[4];
-  mine[0] = __popc(acc & below[0]);
+  mine[0] = fn_popc(acc & below[0]);
 #pragma unroll
-  for (int i = 1; i < 4; i++) mine[i] = __popc(acc & below[i] & ~below[i - 1]);
-  const int packed = mine[0] | (mine[1] << 8) | (mine[2] << 16) | (mine[3] << 24);  // each <= 24
-  const int partner = quad_xor1(packed);        // the other half of the same four cells
+  for (int i = 1; i < 4; i++) mine[i] = fn_popc(acc & below[i] & ~below[i - 1]);
+  const int packed = mine[0] | (mine[1] << 8) | (mine[2] << 16) | (mine[3] << 24);  // each <= 48
+  const int partner = grp_other_half(packed);   // the other half of the same four cells (none with two lanes per particle)
   const int cellTot = packed + partner;         // whole-cell counts of this pair (bytes <= 48: no carry)
-  const int otherTot = quad_xor2(cellTot);      // whole-cell counts of the other pair
+  const int otherTot = grp_other_pair(cellTot); // whole-cell counts of the other pair
   // (the wave's list area is free from here on: every lane has its slots in slotPk, and LDS operations of a wave retire in order)
   if (!slow) {
     const int c0b = cellTot & 255, c1b = (cellTot >> 8) & 255, c2b = (cellTot >> 16) & 255, c3b = (cellTot >> 24) & 255;
@@ -599,7 +618,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
     // one per list entry, and the distances leave as two 16-byte stores per lane (which also write the -1 of the unused slots).
     int tidNow = tid;  // (opaque: keeps the address below from being hoisted to the kernel's prologue and spilled)
     asm volatile("" : "+v"(tidNow));
-    float* const dstRow = reinterpret_cast<float*>(&sh.list[0][0][0]) + (tidNow >> 6) * (FN_LIST_CAP * 64 / 2) + ((tidNow & 63) >> 2) * FN_DST_STRIDE;
+    float* const dstRow = reinterpret_cast<float*>(&sh.list[0][0][0]) + (tidNow >> 6) * (FN_LIST_CAP * 64 / 2) + ((tidNow & 63) >> FN_LOG_LANES) * FN_DST_STRIDE;
     const uint32_t mapBase = ((uint32_t)(idNow >> 6) * (8u * 64u) + (uint32_t)(idNow & 63)) << 2;  // element index of slot 0 (< 2^32: N <= 2^27)
     // walk the entries in list order with a running (piece start, index delta, rank inside the piece)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
@@ -612,7 +631,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
         if (e == segEnd[0]) { curStart = start[1]; curDelta = absDelta[1]; rank = 0; }  // (empty pieces cascade in order)
         if (e == segEnd[1]) { curStart = start[2]; curDelta = absDelta[2]; rank = 0; }
         if (e == segEnd[2]) { curStart = start[3]; curDelta = absDelta[3]; rank = 0; }
-        if ((acc >> e) & 1u) {
+        if ((acc >> e) & 1) {
           const int pos = curStart + rank;
           rank++;
           if (pos < SPH_MAXN) {
@@ -623,14 +642,16 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
       }
     }
     for (int k = run + quadLane; k < SPH_MAXN; k += FN_LANES) nbrId[mapBase + (uint32_t)(((k >> 2) << 8) + (k & 3))] = -1;  // K1 folded in: unused id slots
-    const f32x4 da = *reinterpret_cast<const f32x4*>(dstRow + 8 * quadLane), db = *reinterpret_cast<const f32x4*>(dstRow + 8 * quadLane + 4);
-    const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-    float out[8];
+    const uint32_t mapMine = mapBase + (uint32_t)((FN_SLOTS_PER_LANE / 4) * quadLane) * 256u;  // this lane's first group of 4 slots
 #pragma unroll
-    for (int j = 0; j < 8; j++) out[j] = (8 * quadLane + j < run) ? sqrtf(dv[j]) * d.simScale : -1.f;
-    float* const distBase = nbrDist + (size_t)(mapBase + (uint32_t)(2 * quadLane) * 256u);
-    *reinterpret_cast<f32x4*>(distBase) = f32x4{out[0], out[1], out[2], out[3]};
-    *reinterpret_cast<f32x4*>(distBase + 256) = f32x4{out[4], out[5], out[6], out[7]};
+    for (int gq = 0; gq < FN_SLOTS_PER_LANE / 4; gq++) {
+      const f32x4 dq = *reinterpret_cast<const f32x4*>(dstRow + FN_SLOTS_PER_LANE * quadLane + 4 * gq);
+      const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) out[j] = (FN_SLOTS_PER_LANE * quadLane + 4 * gq + j < run) ? sqrtf(dv[j]) * d.simScale : -1.f;
+      *reinterpret_cast<f32x4*>(nbrDist + (size_t)(mapMine + (uint32_t)gq * 256u)) = f32x4{out[0], out[1], out[2], out[3]};
+    }
   }
   FN_STAMP(8)
   }  // mine_now
@@ -641,7 +662,7 @@ __global__ __launch_bounds__(FN_THREADS, 4) void k_find_neighbors(FnParams d, co
     while (todo != 0ull) {
       const int b = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
-      fn_exact_walk(d, g, sh, p0 + wave * 16 + (b >> 2), wave, lane);
+      fn_exact_walk(d, g, sh, p0 + wave * FN_PER_WAVE + (b >> FN_LOG_LANES), wave, lane);
     }
   }
   FN_STAMP(9)

@@ -16,7 +16,7 @@ h.synchronize()
 c = h.buffer("debugCounters").astype(float)
 names = ["head (bounds, run table)", "-", "-", "candidate loads + barrier", "setup", "walk", "expand", "bisect", "pass1+store", "exact walks"]
 tot = c[16:26].sum()
-waves = reps * ((sc["cfg"].particleCount + 127) // 128) * 8
+waves = reps * ((sc["cfg"].particleCount + 127) // 128) * int(os.environ.get("FN_WAVES", "4"))
 print("phase shares (cycles per wave in brackets):")
 for i, n in enumerate(names):
     print("  %-22s %5.1f %%  [%7.0f]" % (n, 100 * c[16 + i] / max(tot, 1), 64 * c[16 + i] / waves))
