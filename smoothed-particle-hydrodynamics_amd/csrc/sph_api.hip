@@ -191,9 +191,9 @@ static bool two_hip_runtimes(char* out, size_t cap) {
 
 static void free_all(sph_solver* s) {
   SphDev& d = s->d;
-  void* ptrs[] = {d.elasticMask, d.velRho, d.bndMask, d.posPress, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
-                  d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho, d.rhoPred,
-                  d.pressure, d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
+  void* ptrs[] = {d.elasticMask, d.bndMask, d.rp, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
+                  d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho,
+                  d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
                   s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->slabHost) hipHostFree(s->slabHost);
@@ -302,11 +302,11 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   int rc = SPH_OK;
   const size_t n = (size_t)cap, nUp = (size_t)N, G1 = (size_t)d.G + 1, mapN = (size_t)s->capTiles * 64 * 32;
 #define A(ptr, count) if (rc == SPH_OK) rc = dev_alloc(&(ptr), (count))
-  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.posPress, n); A(d.bndMask, n); A(d.velRho, n);
+  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.rp, n); A(d.bndMask, n);
   A(d.keys, n); A(d.vals, n); A(d.keysAlt, n); A(d.valsAlt, n); A(d.backIndex, n);
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
   A(d.nbrId, mapN); A(d.nbrDist, mapN);
-  A(d.rho, n); A(d.rhoPred, n); A(d.pressure, n);
+  A(d.rho, n);
   A(s->blockHist, (size_t)256 * s->maxSortBlocks + 256);  // [256][maxSortBlocks] block histograms + 256 digit totals
   A(d.gid, n); A(d.owned, n); A(s->slabCounts, 12);
   A(d.dbg, SPH_DBG_WORDS);
@@ -345,8 +345,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   hipMemsetAsync(d.acc, 0, sizeof(float4) * n, s->stream);
   hipMemsetAsync(d.accP, 0, sizeof(float4) * n, s->stream);
   hipMemsetAsync(d.rho, 0, sizeof(float) * n, s->stream);
-  hipMemsetAsync(d.rhoPred, 0, sizeof(float) * n, s->stream);
-  hipMemsetAsync(d.pressure, 0, sizeof(float) * n, s->stream);
+  hipMemsetAsync(d.rp, 0, sizeof(float2) * n, s->stream);
   hipMemsetAsync(d.nbrId, 0xff, sizeof(int32_t) * mapN, s->stream);
   hipMemsetAsync(d.nbrDist, 0, sizeof(float) * mapN, s->stream);
   hipMemsetAsync(d.dbg, 0, sizeof(uint32_t) * SPH_DBG_WORDS, s->stream);
@@ -521,7 +520,7 @@ static int enqueue_step(sph_solver* s, const StepTail* tail) {
   if (s->d.hasElastic) RUN(SPH_ST_ELASTIC, sphk_elastic(s));
   for (int iter = 0; iter < M; iter++) {
     const int left = M - 1 - iter;  // iterations after this one
-    RUN(SPH_ST_PREDICT_DENSITY, sphk_predict_density(s, true, layersFor(2 * left + 1)));
+    RUN(SPH_ST_PREDICT_DENSITY, sphk_predict_density(s, true, layersFor(2 * left + 1), iter == 0));
     if (left > 0 || !tail) { RUN(SPH_ST_PRESSURE_FORCE, sphk_pressure_force(s, left == 0 ? 2 : 1, layersFor(2 * left))); continue; }
     // ---- overlapped tail. A particle that ends the step within W layers of a cut started it within W + 1 layers (particles
     // move less than one layer per step — the same assumption the ghost depth rests on), so integrating the W + 1 owned
@@ -689,12 +688,20 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
     case B_PIB: rc = d2h(s, o, d.backIndex, sizeof(uint32_t) * n); break;
     case B_GCI: rc = d2h(s, o, d.cellStartRaw, sizeof(uint32_t) * G1); break;
     case B_GCIF: rc = d2h(s, o, d.cellStart, sizeof(uint32_t) * G1); break;
-    case B_P: rc = d2h(s, o, d.pressure, sizeof(float) * n); break;
+    case B_P: {
+      std::vector<float2> rp(n);
+      rc = d2h(s, rp.data(), d.rp, sizeof(float2) * n);
+      if (rc == SPH_OK) for (size_t i = 0; i < n; i++) ((float*)o)[i] = rp[i].y;
+    } break;
     case B_TRACE: rc = d2h(s, o, d.valsAlt, sizeof(uint32_t) * n); break;
     case B_DBG: rc = d2h(s, o, d.dbg, sizeof(uint32_t) * SPH_DBG_WORDS); break;
     case B_RHO:
       rc = d2h(s, o, d.rho, sizeof(float) * n);
-      if (rc == SPH_OK) rc = d2h(s, o + sizeof(float) * n, d.rhoPred, sizeof(float) * n);
+      if (rc == SPH_OK) {
+        std::vector<float2> rp(n);
+        rc = d2h(s, rp.data(), d.rp, sizeof(float2) * n);
+        if (rc == SPH_OK) for (size_t i = 0; i < n; i++) ((float*)o)[n + i] = rp[i].x;
+      }
       break;
   }
   return rc;

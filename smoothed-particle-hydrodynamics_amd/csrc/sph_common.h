@@ -3,7 +3,7 @@
 //   orig order (API state)      posOrig  float4[N] (x,y,z,type)        velOrig float4[N] (vx,vy,vz,w)
 //   sorted order (per step)     sortedPos float4[N] (x,y,z,type)       sortedVel float4[N]     predPos float4[N]
 //                               keys u32[N] (cell)  vals u32[N] (orig id)  backIndex u32[N] (orig -> sorted)
-//                               rho / rhoPred / pressure f32[N]        acc / accP float4[N]
+//                               rho f32[N]   rp float2[N] (rhoPred, pressure)   acc / accP float4[N]
 //   neighbour map, tiled        nbrId i32, nbrDist f32: [tile = id/64][group = slot/4][lane = id%64][slot%4]
 //                               -> one wave reads 4 slots of its 64 particles as ONE contiguous 1-KiB transaction
 //   grid                        cellStart u32[G+1]  (== gridCellIndexFixedUp: #particles with cell < c)
@@ -48,16 +48,15 @@ struct SphDev {  // what the kernels see; passed by value
   // buffers
   float4 *posOrig, *velOrig, *membDelta;
   float4 *sortedPos, *sortedVel, *predPos, *acc, *accP;
-  float4* velRho;     // (sortedVel.xyz, rho): what the forces kernel gathers per neighbour besides the position
   uint32_t* elasticMask;  // bit k set: neighbour slot k holds an elastic particle (forces kernel -> membrane kernel)
   uint32_t* bndMask;  // bit k set: neighbour slot k holds a boundary particle (written by the forces kernel, read by integrate)
-  float4* posPress;  // (sortedPos.xyz, pressure): what the pressure-force kernel gathers per neighbour, one 16-B load
+  float2* rp;        // (rhoPred, pressure) per sorted particle: one 8-byte record, gathered per neighbour by the pressure-force kernel
   uint32_t *keys, *vals, *keysAlt, *valsAlt, *backIndex;
   uint32_t *cellStart, *cellStartRaw;
   uint32_t *gid, *owned;  // slab decomposition: global id and ownership flag per local particle (orig order)
   int32_t* nbrId;
   float* nbrDist;
-  float *rho, *rhoPred, *pressure;
+  float* rho;
   float4* elastic;
   int32_t *membraneData, *pml;
   float* muscle;
@@ -147,7 +146,7 @@ int sphk_density(sph_solver* s, int ghostDepth = -1);
 int sphk_forces(sph_solver* s, bool fusePredict, int ghostDepth = -1);
 int sphk_ghost_init(sph_solver* s);  // what K7 does besides the acceleration, for every particle (slab mode)
 int sphk_predict_positions(sph_solver* s);
-int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth = -1);
+int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth = -1, bool first = false);  // first: fused step, iteration 0
 int sphk_correct_pressure(sph_solver* s);
 int sphk_pressure_force(sph_solver* s, int fuse, int ghostDepth = -1);  // 0 none, 1 + predictPositions, 2 + integrate
 int sphk_integrate(sph_solver* s);

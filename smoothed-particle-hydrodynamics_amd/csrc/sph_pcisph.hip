@@ -150,8 +150,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
   const float4 xi = d.sortedPos[id];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
-    d.acc[id] = zero; d.accP[id] = zero; d.pressure[id] = 0.f;
+    d.acc[id] = zero;
     if (FUSE_PREDICT) d.predPos[id] = xi;
+    else { d.accP[id] = zero; d.rp[id].y = 0.f; }  // (fused step: nobody reads either before the next kernel overwrites it)
     return;
   }
   const float4 vi = d.sortedVel[id];
@@ -177,11 +178,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
       rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
     }
     float4 xj[FC_BATCH], vj[FC_BATCH];
+    float rhoj[FC_BATCH];
 #pragma unroll
     for (int k = 0; k < FC_BATCH; k++) {
       const int jc = max(jj[k], 0);
       xj[k] = d.sortedPos[jc];
-      vj[k] = d.velRho[jc];  // (v.xyz, rho); for a boundary neighbour v is its wall normal (sphFluid.cl:653)
+      vj[k] = d.sortedVel[jc];  // for a boundary neighbour v is its wall normal (sphFluid.cl:653)
+      rhoj[k] = d.rho[jc];
     }
 #pragma unroll
     for (int k = 0; k < FC_BATCH; k++) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
       if (valid && TYPE_OF(xj[k]) == SPH_BOUNDARY_PARTICLE) bnd |= 1u << slot;
       if (valid && TYPE_OF(xj[k]) == SPH_ELASTIC_PARTICLE) ela |= 1u << slot;
       const bool use = valid && rr[k] < d.hs;
-      const float rj = vj[k].w;
+      const float rj = rhoj[k];
       const float w = d.hs - rr[k];
       sx = use ? sx + (vj[k].x - vi.x) * w / rj : sx;
       sy = use ? sy + (vj[k].y - vi.y) * w / rj : sy;
@@ -209,28 +212,18 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
   a.z = sz * scale + d.gravz + tz;
   a.w = 0.f;  // acceleration.w is never read (integrate zeroes it, sphFluid.cl:1721)
   d.acc[id] = a;
-  d.accP[id] = zero;
-  d.pressure[id] = 0.f;
+  // The staged API needs pressure = 0 and a zero pressure acceleration in memory; in the fused step the first predictDensity
+  // starts from p = 0 by itself and the pressure acceleration is not read before the last pressure-force kernel writes it.
   if (FUSE_PREDICT) d.predPos[id] = predict_position(d, xi, vi, zero);
-}
-
-// (sortedVel.xyz, rho) records for the neighbour gathers of the forces kernel: one 16-B gather instead of 16 B + 4 B.
-// Kept out of k_density so that the roofline-graded pass moves exactly its 132 B per particle.
-__global__ __launch_bounds__(SPH_BLOCK) void k_pack_vel_rho(SphDev d) {
-  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (id >= d.N) return;
-  const float4 v = d.sortedVel[id];
-  d.velRho[id] = make_float4(v.x, v.y, v.z, d.rho[id]);
+  else { d.accP[id] = zero; d.rp[id].y = 0.f; }
 }
 
 // Slab mode: forces are only needed on the owned layers, but every local particle needs what K7 does besides the
-// acceleration — pressure = 0, pressure acceleration = 0 and (fused) the iteration-0 predicted position.
+// acceleration — the iteration-0 predicted position (pressure = 0 is implied by the first fused predictDensity).
 __global__ __launch_bounds__(SPH_BLOCK) void k_ghost_init(SphDev d) {
   const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (id >= d.N) return;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  d.accP[id] = zero;
-  d.pressure[id] = 0.f;
   d.predPos[id] = predict_position(d, d.sortedPos[id], d.sortedVel[id], zero);
 }
 
@@ -243,7 +236,6 @@ int sphk_ghost_init(sph_solver* s) {
 int sphk_forces(sph_solver* s, bool fusePredict, int ghostDepth) {
   const int nb = sph_blocks(s->d.N);
   const SphDev d = sph_ranged(s, ghostDepth);
-  hipLaunchKernelGGL(k_pack_vel_rho, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d);
   if (fusePredict) hipLaunchKernelGGL((k_forces<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   else hipLaunchKernelGGL((k_forces<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
@@ -259,7 +251,8 @@ __device__ __forceinline__ float corrected_pressure(const SphDev& d, float p, fl
   return p + p_corr;
 }
 
-template <bool FUSE_CORRECT>
+// FIRST (fused step, iteration 0): the pressure being corrected is the 0 that K7 sets, without reading it.
+template <bool FUSE_CORRECT, bool FIRST>
 __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nblocks) {
   int id;
   if (!xcd_range_id(d, id)) return;
@@ -295,21 +288,21 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   }
   if (density < (double)d.hs6) density = (double)d.hs6;
   density *= d.massWpoly6;
-  const float rp = (float)density;
-  d.rhoPred[id] = rp;
-  if (FUSE_CORRECT) {
-    const float pnew = corrected_pressure(d, d.pressure[id], rp);
-    d.pressure[id] = pnew;
-    const float4 x = d.sortedPos[id];
-    d.posPress[id] = make_float4(x.x, x.y, x.z, pnew);  // packed for the neighbour gathers of the pressure-force kernel
+  const float rhoP = (float)density;
+  if (FUSE_CORRECT) {  // (rho*, p) is one 8-byte record: what the pressure-force kernel gathers per neighbour besides the position
+    const float pOld = FIRST ? 0.f : d.rp[id].y;
+    d.rp[id] = make_float2(rhoP, corrected_pressure(d, pOld, rhoP));
+  } else {
+    d.rp[id].x = rhoP;
   }
 }
 
-int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth) {
+int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth, bool first) {
   const int nb = sph_blocks(s->d.N);
   const SphDev d = sph_ranged(s, ghostDepth);
-  if (fuseCorrect) hipLaunchKernelGGL((k_predict_density<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
-  else hipLaunchKernelGGL((k_predict_density<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  if (fuseCorrect && first) hipLaunchKernelGGL((k_predict_density<true, true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  else if (fuseCorrect) hipLaunchKernelGGL((k_predict_density<true, false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
+  else hipLaunchKernelGGL((k_predict_density<false, false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -317,10 +310,8 @@ int sphk_predict_density(sph_solver* s, bool fuseCorrect, int ghostDepth) {
 __global__ __launch_bounds__(SPH_BLOCK) void k_correct_pressure(SphDev d) {
   const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (id >= d.N) return;
-  const float pnew = corrected_pressure(d, d.pressure[id], d.rhoPred[id]);
-  d.pressure[id] = pnew;
-  const float4 x = d.sortedPos[id];
-  d.posPress[id] = make_float4(x.x, x.y, x.z, pnew);
+  const float2 v = d.rp[id];
+  d.rp[id].y = corrected_pressure(d, v.y, v.x);
 }
 
 int sphk_correct_pressure(sph_solver* s) {
@@ -417,11 +408,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   const float4 xi = d.sortedPos[id];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TYPE_OF(xi) == SPH_BOUNDARY_PARTICLE) {
-    d.accP[id] = zero;
     if (FUSE == 1) d.predPos[id] = xi;
+    else d.accP[id] = zero;  // (FUSE == 1, a middle iteration of the fused step: the next pressure-force kernel overwrites it unread)
     return;
   }
-  const float pi_ = d.pressure[id];
+  const float2 rpi = d.rp[id];  // (rho*, p) of this particle
+  const float pi_ = rpi.y;
   const NbrTile t(d, id);
   float rx = 0.f, ry = 0.f, rz = 0.f;
   const float hq = d.hs * 0.25f;
@@ -444,16 +436,16 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
       rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
     }
     float4 xj[PF_BATCH];
-    float rpj[PF_BATCH];
+    float2 rpj[PF_BATCH];
 #pragma unroll
-    for (int k = 0; k < PF_BATCH; k++) { const int jc = max(jj[k], 0); xj[k] = d.posPress[jc]; rpj[k] = d.rhoPred[jc]; }
+    for (int k = 0; k < PF_BATCH; k++) { const int jc = max(jj[k], 0); xj[k] = d.sortedPos[jc]; rpj[k] = d.rp[jc]; }
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const float r = rr[k];
       // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
       // the numerator is selected first, so only one IEEE division is spent
-      const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + xj[k].w);
-      const float value = num / rpj[k];
+      const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
+      const float value = num / rpj[k].x;
       const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
       const bool use = jj[k] != -1 && r < d.hs;
       rx = use ? rx + value * vx / r : rx;
@@ -461,9 +453,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
       rz = use ? rz + value * vz / r : rz;
     }
   }
-  const float scale = (float)(d.massGradW / (double)d.rhoPred[id]);
+  const float scale = (float)(d.massGradW / (double)rpi.x);
   const float4 ap = make_float4(rx * scale, ry * scale, rz * scale, 0.f);
-  d.accP[id] = ap;
+  if (FUSE != 1) d.accP[id] = ap;
   if (FUSE == 1) d.predPos[id] = predict_position(d, xi, d.sortedVel[id], ap);
   if (FUSE == 2) integrate_particle(d, id, xi, d.sortedVel[id], d.acc[id], ap);
 }
