@@ -8,6 +8,15 @@
 #include "sph_common.h"
 
 #define TYPE_OF(p4) ((int)(p4).w)
+// DIAGNOSTIC build only (timings, results invalid): DIAG_OWN_GATHER reads the lane's own record instead of the neighbour's, so
+// every gather becomes a coalesced load. A/B on MI355X, config #2: forces 0.148 -> 0.061 ms, predictDensity x3 0.115 -> 0.083,
+// pressure force x3 0.284 -> 0.199: the 16-byte neighbour gathers (64 different cache lines per wave instruction) cost about
+// a fifth of the step; the kernels take the same time per particle at 1 M (cache resident) and at 16.5 M particles.
+#ifdef DIAG_OWN_GATHER
+#define NBR_INDEX(j) (id)
+#else
+#define NBR_INDEX(j) (max((j), 0))
+#endif
 
 // neighbour gathers kept in flight per lane by the branch-free kernels (A/B on MI355X, config #2)
 #ifndef FC_BATCH
@@ -144,7 +153,7 @@ int sphk_predict_positions(sph_solver* s) {
 
 // ------------------------------------------------------------------ K7 pcisph_computeForcesAndInitPressure (sphFluid.cl:589-708)
 template <bool FUSE_PREDICT>
-__global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
+__global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) {  // <= 128 VGPRs: four waves per SIMD
   int id;
   if (!xcd_range_id(d, id)) return;
   const float4 xi = d.sortedPos[id];
@@ -160,30 +169,29 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_forces(SphDev d, int nblocks) {
   float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
   uint32_t bnd = 0u, ela = 0u;  // which neighbour slots hold boundary / elastic particles: saves integrate and the
                                 // membrane kernel 32 type gathers per particle
-  // Branch-free (see k_predict_density): map loads first, both gathers of FC_BATCH neighbours in flight together.
-  int4 j4[8];
-  float4 r4[8];
-#pragma unroll
-  for (int g = 0; g < 8; g++) { j4[g] = t.id4(g); r4[g] = t.dist4(g); }
-#pragma unroll
+  // Branch-free (see k_predict_density): per batch of FC_BATCH neighbours the map loads, then all gathers in flight together.
+  // The map is read batch by batch (not all 32 entries up front) and the velocity gather takes 12 bytes: at 193 VGPRs the
+  // kernel ran two waves per SIMD, too few to cover its gathers.
+  typedef float f3 __attribute__((ext_vector_type(3)));
+#pragma unroll 1  // (a real loop: unrolled, hipcc hoists the loads of all four batches to the top and needs ~190 VGPRs)
   for (int b = 0; b < 32 / FC_BATCH; b++) {
     int jj[FC_BATCH];
     float rr[FC_BATCH];
 #pragma unroll
-    for (int k = 0; k < FC_BATCH; k++) {
-      const int slot = b * FC_BATCH + k;
-      const int4 jq = j4[slot >> 2];
-      const float4 rq = r4[slot >> 2];
-      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
-      rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
+    for (int q = 0; q < FC_BATCH / 4; q++) {
+      const int4 jq = t.id4(b * (FC_BATCH / 4) + q);
+      const float4 rq = t.dist4(b * (FC_BATCH / 4) + q);
+      jj[4 * q] = jq.x; jj[4 * q + 1] = jq.y; jj[4 * q + 2] = jq.z; jj[4 * q + 3] = jq.w;
+      rr[4 * q] = rq.x; rr[4 * q + 1] = rq.y; rr[4 * q + 2] = rq.z; rr[4 * q + 3] = rq.w;
     }
-    float4 xj[FC_BATCH], vj[FC_BATCH];
+    float4 xj[FC_BATCH];
+    f3 vj[FC_BATCH];
     float rhoj[FC_BATCH];
 #pragma unroll
     for (int k = 0; k < FC_BATCH; k++) {
-      const int jc = max(jj[k], 0);
+      const int jc = NBR_INDEX(jj[k]);
       xj[k] = d.sortedPos[jc];
-      vj[k] = d.sortedVel[jc];  // for a boundary neighbour v is its wall normal (sphFluid.cl:653)
+      vj[k] = *reinterpret_cast<const f3*>(&d.sortedVel[jc]);  // for a boundary neighbour v is its wall normal (sphFluid.cl:653)
       rhoj[k] = d.rho[jc];
     }
 #pragma unroll
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
     }
     float4 xj[PD_BATCH];
 #pragma unroll
-    for (int k = 0; k < PD_BATCH; k++) xj[k] = d.predPos[max(jj[k], 0)];
+    for (int k = 0; k < PD_BATCH; k++) xj[k] = d.predPos[NBR_INDEX(jj[k])];
 #pragma unroll
     for (int k = 0; k < PD_BATCH; k++) {
       const float rx = xi.x - xj[k].x, ry = xi.y - xj[k].y, rz = xi.z - xj[k].z;
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
     float4 xj[PF_BATCH];
     float2 rpj[PF_BATCH];
 #pragma unroll
-    for (int k = 0; k < PF_BATCH; k++) { const int jc = max(jj[k], 0); xj[k] = d.sortedPos[jc]; rpj[k] = d.rp[jc]; }
+    for (int k = 0; k < PF_BATCH; k++) { const int jc = NBR_INDEX(jj[k]); xj[k] = d.sortedPos[jc]; rpj[k] = d.rp[jc]; }
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const float r = rr[k];
