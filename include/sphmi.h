@@ -119,6 +119,10 @@ int sph_read_particle_index(sph_solver* s, uint32_t* out2N);
  * pressure[N f32] rho[2N f32]. `bytes` must equal the buffer's size (query with out == NULL: returns the size
  * through *needed). Blocking. */
 int sph_read_buffer(sph_solver* s, const char* name, void* out, size_t bytes, size_t* needed);
+/* The neighbour lists of the SORTED particles [first, first + count) only (a 64 M-particle map is 16 GB): ids[count][32]
+ * (sorted index of the neighbour, -1 = empty slot: neighborMap[].x of the reference, sphFluid.cl:170) and dist[count][32]
+ * (neighborMap[].y: distance * simulationScale, -1 = empty). Either pointer may be NULL. Blocking. */
+int sph_read_neighbor_rows(sph_solver* s, int32_t first, int32_t count, int32_t* ids, float* dist);
 
 int sph_synchronize(sph_solver* s);
 

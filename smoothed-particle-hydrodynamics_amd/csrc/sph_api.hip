@@ -707,6 +707,27 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
   return rc;
 }
 
+extern "C" int sph_read_neighbor_rows(sph_solver* s, int32_t first, int32_t count, int32_t* ids, float* dist) {
+  ENTER(s);
+  if (first < 0 || count < 0 || (long long)first + count > s->d.N) { sph_set_error("sph_read_neighbor_rows: range outside [0, N)"); return SPH_ERR_INVALID; }
+  if (count == 0) return SPH_OK;
+  const size_t t0 = (size_t)first / SPH_TILE, t1 = ((size_t)first + count + SPH_TILE - 1) / SPH_TILE;  // tiles [t0, t1)
+  const size_t words = (t1 - t0) * 64 * 32, base = t0 * 64 * 32;
+  std::vector<int32_t> ti;
+  std::vector<float> td;
+  int rc = SPH_OK;
+  if (ids) { ti.resize(words); rc = d2h(s, ti.data(), s->d.nbrId + base, sizeof(int32_t) * words); }
+  if (rc == SPH_OK && dist) { td.resize(words); rc = d2h(s, td.data(), s->d.nbrDist + base, sizeof(float) * words); }
+  if (rc != SPH_OK) return rc;
+  for (int32_t i = 0; i < count; i++)
+    for (int k = 0; k < 32; k++) {
+      const size_t src = nbr_index(first + i, k) - base;
+      if (ids) ids[(size_t)i * 32 + k] = ti[src];
+      if (dist) dist[(size_t)i * 32 + k] = td[src];
+    }
+  return SPH_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- slab decomposition
 extern "C" int sph_particle_count(sph_solver* s) { return s ? s->d.N : SPH_ERR_INVALID; }
 

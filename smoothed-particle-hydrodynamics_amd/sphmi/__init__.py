@@ -89,7 +89,7 @@ _STAGE_FUNCS = ["sph_run_clear_buffers", "sph_run_hash_particles", "sph_run_sort
                 "sph_run_compute_interaction_with_membranes", "sph_run_compute_interaction_with_membranes_finalize"]
 EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sph_step", "sph_update_muscles",
                     "sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index",
-                    "sph_read_buffer", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
+                    "sph_read_buffer", "sph_read_neighbor_rows", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
                     "sph_reset_stage_times", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed", "sph_slab_step_begin", "sph_slab_step_messages",
                     "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
@@ -148,6 +148,7 @@ def device_lib():
         for f in ["sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index"]:
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
         L.sph_read_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.sph_read_neighbor_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.sph_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
         L.sph_get_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
         L.sph_last_error.restype = C.c_char_p
@@ -400,6 +401,13 @@ class owHIPSolver:
         out = np.empty(need.value // np.dtype(_BUF_DTYPE[name]).itemsize, _BUF_DTYPE[name])
         self._chk(self._L.sph_read_buffer(self._h, name.encode(), _ptr(out), need.value, None))
         return out
+
+    def neighbor_rows(self, first, count):
+        """Neighbour ids and scaled distances of the sorted particles [first, first + count): two (count, 32) arrays."""
+        ids = np.empty((count, 32), np.int32)
+        dist = np.empty((count, 32), np.float32)
+        self._chk(self._L.sph_read_neighbor_rows(self._h, first, count, _ptr(ids), _ptr(dist)))
+        return ids, dist
 
     # --- slab decomposition (include/sphmi.h, "Spatial decomposition") ---
     def slab_init(self, slab, global_ids):

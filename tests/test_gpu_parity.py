@@ -275,6 +275,114 @@ def test_config4_sixteen_million_box_properties():
     assert scenes.bits_equal(rho.astype(np.float32), hip.read_density_buffer())
 
 
+def test_wide_mode_million_particles_full_steps_against_oracle():
+    """Wide cell ids at scale, FULL steps: 1.07 M particles on a grid of 152,561 declared cells (3 radix passes, ids > 2^16),
+    three fused steps compared with the oracle word for word in every buffer (search structures, neighbour ids and distances,
+    densities, pressures, accelerations, predicted / sorted / final positions, velocities)."""
+    sc = scenes.liquid_box((60.0, 40.0, 60.0), (110, 80, 110), mask=0xffffffff, jitter_in_r0=0.02)
+    cfg = sc["cfg"]
+    N = cfg.particleCount
+    assert N > 1000000 and cfg.gridCellCount > 65536
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16)
+    for it in range(3):
+        hip.step(it)
+        ora.step()
+        keys, _ = _check_search_structures(hip, cfg, N)
+        assert keys.max() > 65535
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "wide 1M, step %d" % it, FUSED_SKIP)
+    ora.close()
+
+
+def test_config5_sixty_four_million_dam_break_properties():
+    """BASELINE config #5 at full size on one GPU (65,469,208 particles: a 250 x 400 x 640 liquid column at low x in a 240h x 200h x
+    310h box, wide cell ids, 15 M declared cells, 31 GB of device state). The oracle cannot run it in a test, so: the search
+    structures in full (sorted keys with ascending-id ties, permutation + inverse, cell table = lower_bound); in three windows
+    of 2^18 sorted particles (start, liquid bulk, end) every stored neighbour distance recomputed bit for bit from the sorted
+    positions, inside the search radius, no self / duplicate neighbours, empty slots last, and the density recomputed from the
+    stored distances in slot order equal bit for bit; then two full fused steps: everything finite, boundary particles
+    untouched, the column falling (mean stored vy of the liquid = g dt to 1e-3)."""
+    sc = scenes.liquid_box((240.0, 200.0, 310.0), (250, 400, 640), mask=0xffffffff)
+    cfg = sc["cfg"]
+    N = cfg.particleCount
+    assert N == 65469208
+    nl = sc["numOfLiquidP"]
+    hip = scenes.hip_for(sc)
+    hip._runClearBuffers(); hip._runHashParticles(); hip._runSort(); hip._runSortPostPass(); hip._runIndexx()
+    hip._runIndexPostPass(); hip._runFindNeighbors(); hip._run_pcisph_computeDensity()
+    keys, vals = _check_search_structures(hip, cfg, N)
+    assert keys.max() > 65535
+    is_liquid = vals < nl  # (liquid_box puts the liquid lattice first; the exported sortedPosition.w is the cell id)
+    del vals
+    spos = hip.buffer("sortedPosition").reshape(-1, 4)[:N, :3].copy()
+    rho_gpu = hip.read_density_buffer()
+    simScale, h = np.float32(cfg.simulationScale), np.float32(cfg.h)
+    rmax2 = (np.float32(31) * h / np.float32(30)) ** 2
+    hs2 = (h * simScale) * (h * simScale)
+    hs6 = np.float64((hs2 * hs2) * hs2)
+    W = 1 << 18
+    liquid_sorted = np.flatnonzero(is_liquid)
+    mid = int(liquid_sorted[liquid_sorted.size // 2]) // 64 * 64
+    for first in (0, mid, N - W):
+        ids, dist = hip.neighbor_rows(first, W)
+        valid = ids >= 0
+        assert np.array_equal(valid, dist != -1.0)
+        assert np.all(np.cumsum(~valid, axis=1)[valid] == 0), "empty slots must come last"
+        own = np.arange(first, first + W, dtype=np.int64)
+        rho = np.zeros(W, np.float64)
+        for k in range(32):
+            v = valid[:, k]
+            j = ids[:, k].astype(np.int64)
+            assert not np.any(j[v] == own[v]), "a particle lists itself"
+            if k:
+                assert not np.any(v & (ids[:, k] == ids[:, k - 1])), "duplicate neighbour"
+            e = spos[own[v]] - spos[j[v]]
+            d2 = (e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2]
+            assert np.all(d2 <= rmax2)
+            assert scenes.bits_equal(np.sqrt(d2) * simScale, dist[v, k]), "slot %d: stored distance != sqrt(d2)*simulationScale" % k
+            a = hs2 - dist[:, k] * dist[:, k]
+            rho += np.where(v, (a * a * a).astype(np.float64), 0.0)
+        rho = np.maximum(rho, hs6) * (np.float64(np.float32(cfg.mass)) * np.float64(cfg.Wpoly6Coefficient))
+        assert scenes.bits_equal(rho.astype(np.float32), rho_gpu[first:first + W])
+        if first == mid:
+            liq = is_liquid[first:first + W]
+            assert liq.sum() > W // 4 and valid[liq].sum() > 24 * liq.sum(), "the liquid bulk must have (nearly) full lists"
+    del spos, keys
+    for it in range(2):
+        hip.step(it)
+    pos, vel = hip.read_position_buffer(), hip.read_velocity_buffer()
+    assert np.all(np.isfinite(pos)) and np.all(np.isfinite(vel))
+    assert scenes.bits_equal(pos[nl:], sc["position"][nl:]), "boundary particles must not move"
+    g_dt = np.float64(cfg.gravity_y) * np.float64(cfg.timeStep)
+    # the stored velocity is the average of old and new (SURVEY App. B #15): from rest 0.5 g dt after one step, (0.5 + 1.5) / 2 = 1.0 g dt
+    # after two; pressure and viscosity forces are pairwise and cancel in the mean
+    assert abs(vel[:nl, 1].astype(np.float64).mean() / g_dt - 1.0) < 1e-3
+
+
+def test_two_solvers_in_one_process():
+    """Two solvers side by side in one process (own streams; on a second device too where the box has one): the dynamic-LDS opt-in
+    of the search kernel is per device, and neither solver disturbs the other's state."""
+    import torch
+    sc = scenes.SCENES["tiny_jitter"]()
+    N = sc["cfg"].particleCount
+    ora = scenes.oracle_for(sc)
+    for _ in range(2):
+        ora.step()
+    want = ora.buffer("position").reshape(-1, 4)[:N]
+    devices = [0, 1] if torch.cuda.device_count() > 1 else [0, 0]
+    solvers = []
+    for dev in devices:
+        s2 = scenes.SCENES["tiny_jitter"]()
+        s2["cfg"].device = dev
+        solvers.append(scenes.hip_for(s2))
+    for it in range(2):          # interleaved: a, b, a, b
+        for hs in solvers:
+            hs.step(it)
+    for hs in solvers:
+        assert scenes.bits_equal(hs.read_position_buffer(), want)
+        assert np.array_equal(hs.buffer("neighborIds"), ora.buffer("neighborIds"))
+    ora.close()
+
+
 def test_ragged_sizes_and_single_particle_cells():
     """N not a multiple of 64/256/4096, and a sparse scene where most cells hold one particle."""
     for lattice, spacing in (((7, 5, 3), 0.93), ((3, 3, 3), 2.9), ((1, 1, 1), 0.93)):
