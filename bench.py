@@ -229,6 +229,14 @@ def main():
         partition_ok = bool(int(stats[0].item()) == N and int(stats[1].item()) == world
                             and abs(stats[2].item() - N * (N - 1) / 2.0) < 0.5)  # every global id exactly once
 
+    per_rank = None  # every rank's local particle count, bytes sent and host time spent in the exchange (waits included)
+    if decomposition is not None:
+        mine = torch.tensor([float(solver.N), float(decomposition.bytes_sent), float(getattr(decomposition, "exchange_seconds", 0.0))],
+                            dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = np.stack([g.cpu().numpy() for g in gathered])
+
     # SURVEY 8(d) extras, single GPU only and outside `value`: per-step p50 from one event pair per step, and the step
     # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step).
     p50_ms, readback_ms = None, None
@@ -333,8 +341,9 @@ def main():
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if decomposition is not None:
-            out["halo"] = {"local_particles_rank0": solver.N, "bytes_sent_rank0_per_step": decomposition.bytes_sent // max(1, it),
-                           "exchange_host_ms_per_step_rank0": round(decomposition.exchange_seconds * 1e3 / max(1, it), 4),
+            out["halo"] = {"local_particles_per_rank": per_rank[:, 0].astype(int).tolist(),
+                           "bytes_sent_per_step_per_rank": (per_rank[:, 1] / max(1, it)).astype(int).tolist(),
+                           "exchange_host_ms_per_step_per_rank": [round(v * 1e3 / max(1, it), 4) for v in per_rank[:, 2]],
                            "p2p_groups_per_step_rank0": round(decomposition.transfers / max(1, it), 3),
                            "owned_sets_partition_all_particles": partition_ok}
         print(json.dumps(out))

@@ -544,6 +544,7 @@ static int enqueue_step(sph_solver* s, const StepTail* tail) {
     if (rc != SPH_OK) return rc;
     SPH_HIP(hipMemcpyAsync(s->slabHost + 8, s->slabCounts + 8, sizeof(uint32_t) * 3, hipMemcpyDeviceToHost, s->stream));
     SPH_HIP(hipMemcpyAsync(s->slabHost + 3, s->slabCounts + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SPH_HIP(hipMemcpyAsync(s->slabHost + 7, s->slabCounts + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   }
   if (s->d.hasElastic) {
     RUN(SPH_ST_MEMBRANES, sphk_clear_membranes(s));
@@ -756,11 +757,19 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
   return SPH_OK;
 }
 
+// An owned particle moved more than one cell layer in a step: the assumption behind the halo depth (include/sphmi.h) is broken
+static int slab_motion_error(sph_solver* s, uint32_t n) {
+  hipMemsetAsync(s->slabCounts + 7, 0, sizeof(uint32_t), s->stream);
+  sph_set_error("%u owned particle(s) moved more than one cell layer in one step: the %d-layer halo no longer guarantees "
+                "single-domain results (time step too large for these velocities?)", n, s->slab.ghostLayers);
+  return SPH_ERR_INVALID;
+}
+
 static int slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int32_t capRecords, int32_t counts[3], uint32_t* headDown,
                      uint32_t* headUp) {
   int rc = sphk_slab_pack(s, msgDown, msgUp, capRecords, headDown, headUp);
   if (rc != SPH_OK) return rc;
-  uint32_t h[4];
+  uint32_t h[8];
   SPH_HIP(hipMemcpyAsync(h, s->slabCounts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
   SPH_HIP(hipStreamSynchronize(s->stream));
   counts[0] = (int32_t)h[0]; counts[1] = (int32_t)h[1]; counts[2] = (int32_t)h[2];
@@ -769,6 +778,7 @@ static int slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int32_t 
     sph_set_error("a halo message passed to the last sph_slab_rebuild was not sorted by global id");
     return SPH_ERR_INVALID;
   }
+  if (h[7]) return slab_motion_error(s, h[7]);
   s->slabKept = (int)h[0];
   if ((int)h[1] > capRecords || (int)h[2] > capRecords) { sph_set_error("halo message overflow: %u / %u records, room for %d", h[1], h[2], capRecords); return SPH_ERR_SIZE; }
   return SPH_OK;
@@ -830,6 +840,7 @@ extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDo
       sph_set_error("a halo message passed to the last sph_slab_rebuild was not sorted by global id");
       return SPH_ERR_INVALID;
     }
+    if (s->slabHost[7]) return slab_motion_error(s, s->slabHost[7]);
     s->slabKept = (int)s->slabHost[8];
   }
   if (s->slabKept < 0) { sph_set_error("sph_slab_rebuild without a preceding sph_slab_pack"); return SPH_ERR_ORDER; }

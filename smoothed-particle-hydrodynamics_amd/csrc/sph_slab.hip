@@ -20,13 +20,20 @@ __device__ __forceinline__ void put_record(uint32_t* msg, uint32_t j, const floa
 //   k_slab_pack<false>  per workgroup of 2048 particles, how many go to each of the three destinations
 //   k_slab_scan         exclusive scan of those counts over the workgroups (one workgroup) + the three totals
 //   k_slab_pack<true>   the same flags again, slot = workgroup offset + rank inside the workgroup (ballot prefixes)
+// owned[] holds 0 for ghosts and 1 + (z layer - slab_base) for owned particles, so that the pack can tell how far a particle moved
+__host__ __device__ static inline int slab_base(const sph_slab& slab) { return slab.hasLower ? slab.layerLo - 1 : 0; }
+__device__ __forceinline__ uint32_t owned_code(const sph_slab& slab, int layer) {
+  return (layer >= slab.layerLo && layer < slab.layerHi) ? (uint32_t)(layer - slab_base(slab) + 1) : 0u;
+}
+
 #define PACK_ITEMS 8
 #define PACK_SPAN (SPH_BLOCK * PACK_ITEMS)
 
 template <bool WRITE>
 __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab, uint32_t* __restrict__ blockCounts,
                                                          const uint32_t* __restrict__ blockOffsets, uint32_t* __restrict__ msgDown,
-                                                         uint32_t* __restrict__ msgUp, int capRecords, SlabPart part) {
+                                                         uint32_t* __restrict__ msgUp, int capRecords, SlabPart part,
+                                                         uint32_t* __restrict__ moved) {
   __shared__ uint32_t tot[PACK_ITEMS * (SPH_BLOCK / 64)][3];  // hits per (round, wave), then their exclusive prefix
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -40,7 +47,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab
   for (int u = 0; u < PACK_ITEMS; u++) {  // element order inside the workgroup: (round u, thread) = ascending particle index
     const int i = first + u * SPH_BLOCK;
     uint32_t f = 0u;
-    if (i < d.N && d.owned[i]) {
+    const uint32_t ownedAt = (i < d.N) ? d.owned[i] : 0u;  // 0: ghost; otherwise 1 + (z layer at the last rebuild) - slabBase
+    if (ownedAt) {
       bool final_ = true;  // messages-only pass of the overlapped step: only particles that have been integrated already
       if (part.mode == SLAB_PART_MESSAGES) {
         const int sid = (int)d.backIndex[i];
@@ -48,6 +56,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab
       }
       if (final_) {
         const int layer = (int)(d.posOrig[i].z * d.cellSizeInv);  // the z cell coordinate hashParticles uses (sphFluid.cl:199)
+        // The 4-layer halo, the ranged stage launches and the overlapped tail all rest on "a particle moves less than one cell
+        // layer per step": count the owned particles that did not (reported as SPH_ERR_INVALID by the host side of the pack).
+        if (!WRITE && abs(layer - ((int)ownedAt - 1 + slab_base(slab))) > 1) atomicAdd(moved, 1u);
         if (part.mode != SLAB_PART_MESSAGES) f = 1u;
         if (part.mode != SLAB_PART_KEPT) {
           if (slab.hasLower && layer < slab.layerLo + slab.ghostLayers) f |= 2u;
@@ -134,9 +145,9 @@ int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRec
   uint32_t* blockCounts = s->blockHist;  // the radix-sort workspace is idle between two steps: >= capacity/16 words
   uint32_t* blockOffsets = s->blockHist + (size_t)nb * 4;
   if (!counts) counts = s->slabCounts;
-  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part);
+  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part, s->slabCounts + 7);
   hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, counts, headDown, headUp);
-  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part);
+  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part, s->slabCounts + 7);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -155,8 +166,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_gather(SphDev d, sph_slab sl
   d.posOrig[i] = p;
   d.velOrig[i] = d.sortedVel[src];
   d.gid[i] = d.keys[i];
-  const int layer = (int)(p.z * d.cellSizeInv);
-  d.owned[i] = (layer >= slab.layerLo && layer < slab.layerHi) ? 1u : 0u;
+  d.owned[i] = owned_code(slab, (int)(p.z * d.cellSizeInv));
 }
 
 // ---- rebuild by three-way merge. The kept set (staging: sortedPos / sortedVel / keys) and both received messages are
@@ -177,8 +187,7 @@ __device__ __forceinline__ void place_particle(const SphDev& d, const sph_slab& 
   d.posOrig[at] = p;
   d.velOrig[at] = v;
   d.gid[at] = g;
-  const int layer = (int)(p.z * d.cellSizeInv);
-  d.owned[at] = (layer >= slab.layerLo && layer < slab.layerHi) ? 1u : 0u;
+  d.owned[at] = owned_code(slab, (int)(p.z * d.cellSizeInv));
 }
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_kept(SphDev d, sph_slab slab, int kept, const uint32_t* __restrict__ recvDown,

@@ -44,6 +44,13 @@ def balanced_cuts(layers, world, min_thickness=2 * GHOST_LAYERS, ghost_cost=GHOS
     halos only ever involve direct neighbours. Deterministic: every rank computes the same cuts from the same histogram."""
     lo, hi = int(layers.min()), int(layers.max()) + 1
     hist = np.bincount(layers - lo, minlength=hi - lo).astype(np.int64)
+    return balanced_cuts_hist(hist, lo, world, min_thickness, ghost_cost)
+
+
+def balanced_cuts_hist(hist, lo, world, min_thickness=2 * GHOST_LAYERS, ghost_cost=GHOST_COST):
+    """balanced_cuts from the per-layer particle histogram (layer `lo` first) — what the ranks all-gather in a real run."""
+    hist = np.asarray(hist, np.int64)
+    hi = lo + hist.size
     cum = np.concatenate([[0], np.cumsum(hist)])
 
     def count(a, b):  # particles in layers [a, b), clipped to the occupied range

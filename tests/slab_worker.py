@@ -25,11 +25,16 @@ def scene():
     sc = _scene()
     if os.environ.get("SPHMI_TEST_MAXITER"):  # other predict-correct iteration counts change every stage's ghost depth
         sc["cfg"].maxIteration = int(os.environ["SPHMI_TEST_MAXITER"])
+    if os.environ.get("SPHMI_TEST_VZ"):  # the liquid drifts along z (across the cuts): ownership must change hands during the run
+        nl = sc["numOfLiquidP"]
+        sc["velocity"][:nl, 2] = np.float32(os.environ["SPHMI_TEST_VZ"])
     return sc
 
 
 def _scene():
     # wide-mode box, long in z: 30 cell layers, lattice with a little jitter so that particles cross the cut
+    if os.environ.get("SPHMI_TEST_EIGHT_SLABS"):  # 72 layers, thin in x and y: eight slabs of nine layers
+        return scenes.liquid_box((6.0, 6.0, 144.0), (8, 8, 290), mask=0xffffffff, jitter_in_r0=0.05)
     if os.environ.get("SPHMI_TEST_LONG_SCENE"):  # 42 layers: three slabs of 14, so the middle one has an interior between its two cut zones
         return scenes.liquid_box((8.0, 8.0, 84.0), (12, 10, 156), mask=0xffffffff, jitter_in_r0=0.05)
     return scenes.liquid_box((8.0, 8.0, 60.0), (12, 10, 110), mask=0xffffffff, jitter_in_r0=0.05)
@@ -138,8 +143,10 @@ def main():
     for it in range(a.steps):
         counts.append(dd.step(it))
     gid, p, v = backend.owned_state()
+    first_owner = np.searchsorted(np.array(cuts[1:-1]), layers, side="right")  # rank that owned each particle at the start
     np.savez(os.path.join(a.out, "rank%d.npz" % a.rank), gid=gid, pos=p, vel=v, counts=np.array(counts),
-             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers)
+             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers,
+             adopted=int((first_owner[gid.astype(np.int64)] != a.rank).sum()))  # owned now, owned by another rank at the start
     dist.barrier()
     dist.destroy_process_group()
 

@@ -39,18 +39,21 @@ def run_ranks(backend, world, out, steps=STEPS, env=None):
     return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
 
 
-def single_domain_reference(steps=STEPS, long_scene=False, max_iteration=None):
+def single_domain_reference(steps=STEPS, long_scene=False, max_iteration=None, env=None):
     sys.path.insert(0, HERE)
     import slab_worker
+    extra = dict(env or {})
     if long_scene:
-        os.environ["SPHMI_TEST_LONG_SCENE"] = "1"
+        extra["SPHMI_TEST_LONG_SCENE"] = "1"
     if max_iteration:
-        os.environ["SPHMI_TEST_MAXITER"] = str(max_iteration)
+        extra["SPHMI_TEST_MAXITER"] = str(max_iteration)
+    extra = {k: v for k, v in extra.items() if k.startswith("SPHMI_TEST_")}
+    os.environ.update(extra)
     try:
         sc = slab_worker.scene()
     finally:
-        os.environ.pop("SPHMI_TEST_LONG_SCENE", None)
-        os.environ.pop("SPHMI_TEST_MAXITER", None)
+        for k in extra:
+            os.environ.pop(k, None)
     o = scenes.oracle_for(sc, threads=8)
     for _ in range(steps):
         o.step()
@@ -129,6 +132,84 @@ def test_three_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
     results = run_ranks("oracle", 3, tmp_path, steps=3)
     sc, pos_ref, vel_ref = single_domain_reference(steps=3)
     check_union(results, sc, pos_ref, vel_ref)
+
+
+DRIFT = {"SPHMI_TEST_VZ": "0.6"}  # 1.5 units = 0.22 cell layers per step along z: particles cross the cuts within a few steps
+
+
+def test_ownership_changes_hands_cpu(tmp_path):
+    """The liquid drifts across the cuts: particles that started in one slab end up owned by its neighbour (kept as ghost on one
+    side, received as owned on the other); the union is still bit-identical to the single domain."""
+    results = run_ranks("oracle", 3, tmp_path, steps=5, env=DRIFT)
+    sc, pos_ref, vel_ref = single_domain_reference(steps=5, env=DRIFT)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert sum(int(r["adopted"]) for r in results) > 20, "no particle changed owner: the scene does not test the hand-over"
+
+
+def test_eight_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
+    """World size 8 (the node the benchmark targets) on a long thin box: six interior ranks with two neighbours each and two end
+    ranks, nine-layer slabs (one interior layer between the two 4-layer cut zones), liquid drifting across the cuts."""
+    env = dict(DRIFT, SPHMI_TEST_EIGHT_SLABS="1")
+    results = run_ranks("oracle", 8, tmp_path, steps=4, env=env)
+    sc, pos_ref, vel_ref = single_domain_reference(steps=4, env=env)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert sum(int(r["adopted"]) for r in results) > 20
+    assert len(results[0]["cuts"]) == 9
+
+
+def test_balanced_cuts_on_the_benchmark_boxes():
+    """balanced_cuts on the real layer histograms of BASELINE configs #4 (16.5 M box, 235 occupied layers) and #5 (64 M dam break,
+    155 layers) at world 2 / 4 / 8: every rank's cost (owned + 0.75 x ghost particles) within 5 % of the mean, slabs at least
+    2 x GHOST_LAYERS thick, cuts ascending and covering the occupied range."""
+    for box, lattice in (((78.0, 50.0, 470.0), (160, 100, 1000)), ((240.0, 200.0, 310.0), (250, 400, 640))):
+        sc = scenes.liquid_box(box, lattice, mask=0xffffffff)
+        lay = S.particle_layers(sc["position"], sc["cfg"])
+        del sc
+        lo, hi = int(lay.min()), int(lay.max()) + 1
+        hist = np.bincount(lay - lo, minlength=hi - lo).astype(np.int64)
+        del lay
+        cum = np.concatenate([[0], np.cumsum(hist)])
+        for world in (2, 4, 8):
+            cuts = S.balanced_cuts_hist(hist, lo, world)
+            assert cuts[0] == lo and cuts[-1] == hi and all(b - a >= 2 * S.GHOST_LAYERS for a, b in zip(cuts, cuts[1:]))
+            cnt = lambda a, b: int(cum[min(max(b, lo), hi) - lo] - cum[min(max(a, lo), hi) - lo]) if b > a else 0
+            cost = []
+            for r in range(world):
+                a, b = cuts[r], cuts[r + 1]
+                gh = (cnt(a - S.GHOST_LAYERS, a) if r else 0) + (cnt(b, b + S.GHOST_LAYERS) if r < world - 1 else 0)
+                cost.append(cnt(a, b) + S.GHOST_COST * gh)
+            assert max(cost) / (sum(cost) / world) <= 1.05, (box, world, cuts, cost)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_ownership_changes_hands_gpu(tmp_path, overlap):
+    """The same drift through libsphmi's pack / merge kernels, with the overlapped tail (its 'W + 1 layers next to the cut' rule)
+    and with the plain step-then-pack path."""
+    env = dict(DRIFT, SPHMI_SLAB_OVERLAP=overlap)
+    results = run_ranks("hip", 3, tmp_path, steps=5, env=env)
+    sc, pos_ref, vel_ref = single_domain_reference(steps=5, env=env)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert sum(int(r["adopted"]) for r in results) > 20
+
+
+@pytest.mark.gpu
+def test_particle_faster_than_one_layer_per_step_is_reported():
+    """The halo depth assumes < 1 cell layer of motion per step: a particle that breaks it makes the next pack fail loudly."""
+    sc = scenes.liquid_box((8.0, 8.0, 40.0), (12, 10, 60), mask=0xffffffff)
+    cfg = sc["cfg"]
+    n = cfg.particleCount
+    lay = S.particle_layers(sc["position"], cfg)
+    lo, hi = int(lay.min()), int(lay.max()) + 1
+    slab = S.make_slab([lo, (lo + hi) // 2, hi], 0, 2, n)
+    idx = S.local_indices(lay, slab)
+    vel = sc["velocity"][idx].copy()
+    fast = int(np.flatnonzero((lay[idx] == lo + 3) & (sc["position"][idx, 3].astype(int) == 1))[0])
+    vel[fast, 2] = 4.0  # 4.0 * timeStep * simulationScaleInv = 9.9 units = 1.5 cell layers in one step
+    be = S.HipSlabBackend(cfg, sc["position"][idx], vel, idx, slab)
+    be.step(0)
+    with pytest.raises(sphmi.SphError, match="more than one cell layer"):
+        be.pack()
 
 
 @pytest.mark.gpu
