@@ -65,6 +65,8 @@ def lib():
         L.ref_get_constants.argtypes = [C.POINTER(RefConstants)]
         L.ref_generate_scene.argtypes = [C.POINTER(RefScene)]
         L.ref_free_scene.argtypes = [C.POINTER(RefScene)]
+        L.ref_load_configuration.argtypes = [C.c_char_p, C.POINTER(RefScene)]
+        L.ref_save_configuration.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -123,6 +125,35 @@ class RefSolver:
         dt = np.dtype(_BUF_DTYPE[name])
         arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,)).view(dt).copy()
         return arr
+
+
+def load_configuration(directory):
+    """The reference's own owHelper::preLoadConfiguration + loadConfiguration on <directory>/configuration/{position,velocity,
+    elasticconnections}.txt (owHelper.cpp:1431-1545)."""
+    s = RefScene()
+    rc = lib().ref_load_configuration(directory.encode(), C.byref(s))
+    if rc:
+        raise RuntimeError("ref_load_configuration failed: %d" % rc)
+    N, ne = s.N, s.numOfElasticP
+    out = dict(N=N, numOfLiquidP=s.numOfLiquidP, numOfElasticP=ne, numOfBoundaryP=s.numOfBoundaryP,
+               position=np.ctypeslib.as_array(s.position, shape=(N, 4)).copy(),
+               velocity=np.ctypeslib.as_array(s.velocity, shape=(N, 4)).copy(),
+               elastic=np.ctypeslib.as_array(s.elasticConnections, shape=(ne * 32, 4)).copy() if ne else None)
+    lib().ref_free_scene(C.byref(s))
+    return out
+
+
+def save_configuration(directory, position, connections, membranes4, n_elastic, n_liquid, first):
+    """The reference's own owHelper::loadConfigurationToFile (owHelper.cpp:1640-1672) into <directory>/buffers/.
+    membranes4: int32 [M, 4] (the reference indexes its membrane array with stride 4)."""
+    pos = np.ascontiguousarray(position, np.float32)
+    con = None if connections is None else np.ascontiguousarray(connections, np.float32)
+    mem = None if membranes4 is None else np.ascontiguousarray(membranes4, np.int32)
+    rc = lib().ref_save_configuration(directory.encode(), pos.ctypes.data, pos.shape[0], None if con is None else con.ctypes.data,
+                                      None if mem is None else mem.ctypes.data, n_elastic, n_liquid,
+                                      0 if mem is None else mem.shape[0], int(first))
+    if rc:
+        raise RuntimeError("ref_save_configuration failed: %d" % rc)
 
 
 def generate_worm_scene():

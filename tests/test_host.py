@@ -85,6 +85,39 @@ def test_text_loader_roundtrip(tmp_path):
         sphmi.load_configuration(str(tmp_path / "missing.txt"), str(vf))
 
 
+def test_loaders_match_the_reference_loader_fixture():
+    """sphmi_load_configuration / sphmi_load_elastic_connections against owHelper::loadConfiguration ITSELF (compiled into
+    oracle/_ref; fixture tests/golden/ref_loader.npz made by tests/golden/make_io_golden.py): a configuration in the file order of
+    the shipped position.txt (boundary, elastic, liquid) with awkward number formats, blanks instead of tabs, leading blanks and
+    a last line without newline; the connection file is one the reference's own writer produced. Bit for bit."""
+    lo = os.path.join(GOLDEN, "ref_loader")
+    want = np.load(os.path.join(GOLDEN, "ref_loader.npz"))
+    pos, vel, cnt = sphmi.load_configuration(os.path.join(lo, "position.txt"), os.path.join(lo, "velocity.txt"))
+    assert scenes.bits_equal(pos, want["position"]) and scenes.bits_equal(vel, want["velocity"])
+    assert [cnt["numOfLiquidP"], cnt["numOfElasticP"], cnt["numOfBoundaryP"]] == want["counts"].tolist()
+    ne = cnt["numOfElasticP"]
+    con = np.full((32 * ne, 4), np.float32(7.0))
+    con = con.astype(np.float32)
+    rows = sphmi.host_lib().sphmi_load_elastic_connections(os.path.join(lo, "elasticconnections.txt").encode(), ne, con.ctypes.data)
+    assert rows == 32 * ne
+    assert scenes.bits_equal(con, want["elastic"])
+    # the committed config #1 inputs are what the reference loader reads from the shipped PureLiquid files
+    c1 = np.load(os.path.join(GOLDEN, "config1_input.npz"))
+    assert c1["position"].shape == (61440, 4) and int((c1["position"][:, 3].astype(int) == 3).sum()) == 32834
+
+
+def test_trajectory_dump_matches_the_reference_writer_fixture(tmp_path):
+    """sphmi_save_configuration against owHelper::loadConfigurationToFile ITSELF (tests/golden/ref_dump/*.txt, written by the
+    reference's code in oracle/_ref from the arrays in ref_dump_input.npz): header, two frames, connection and membrane files,
+    byte for byte — including operator<< number formatting (1e-07, 123457, 0). Documented deviation: the reference reads its
+    membrane array with stride 4; it was given [i, j, k, 0] rows, sphmi_save_configuration takes the stride-3 table."""
+    z = np.load(os.path.join(GOLDEN, "ref_dump_input.npz"))
+    sphmi.save_configuration(str(tmp_path), z["position"], 3, 5, z["connections"], z["membranes"], first=True)
+    sphmi.save_configuration(str(tmp_path), z["position2"], 3, 5, first=False)
+    for f in ("position_buffer.txt", "connection_buffer.txt", "membranes_buffer.txt"):
+        assert (tmp_path / f).read_bytes() == open(os.path.join(GOLDEN, "ref_dump", f), "rb").read(), f
+
+
 def test_trajectory_dump_format(tmp_path):
     """buffers/*.txt of the reference's -l_to mode (owHelper.cpp:1640-1672): header, non-boundary particles only, appended
     frames, default operator<< float formatting (6 significant digits)."""
