@@ -191,7 +191,7 @@ static bool two_hip_runtimes(char* out, size_t cap) {
 
 static void free_all(sph_solver* s) {
   SphDev& d = s->d;
-  void* ptrs[] = {d.elasticMask, d.bndMask, d.rp, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
+  void* ptrs[] = {d.elasticMask, d.bndMask, d.rp, d.gatherRec, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
                   d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho,
                   d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
                   s->blockHist};
@@ -302,7 +302,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   int rc = SPH_OK;
   const size_t n = (size_t)cap, nUp = (size_t)N, G1 = (size_t)d.G + 1, mapN = (size_t)s->capTiles * 64 * 32;
 #define A(ptr, count) if (rc == SPH_OK) rc = dev_alloc(&(ptr), (count))
-  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.rp, n); A(d.bndMask, n);
+  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.rp, n); A(d.bndMask, n); A(d.gatherRec, 2 * ((n + 3) / 4 * 4));
   A(d.keys, n); A(d.vals, n); A(d.keysAlt, n); A(d.valsAlt, n); A(d.backIndex, n);
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
   A(d.nbrId, mapN); A(d.nbrDist, mapN);

@@ -50,6 +50,7 @@ struct SphDev {  // what the kernels see; passed by value
   float4 *sortedPos, *sortedVel, *predPos, *acc, *accP;
   uint32_t* elasticMask;  // bit k set: neighbour slot k holds an elastic particle (forces kernel -> membrane kernel)
   uint32_t* bndMask;  // bit k set: neighbour slot k holds a boundary particle (written by the forces kernel, read by integrate)
+  float4* gatherRec; // 2 x ceil4(N) float4, groups of four particles [4 x (x,y,z,type)][4 x (v.xyz, rho)]: the forces kernel's neighbour gathers
   float2* rp;        // (rhoPred, pressure) per sorted particle: one 8-byte record, gathered per neighbour by the pressure-force kernel
   uint32_t *keys, *vals, *keysAlt, *valsAlt, *backIndex;
   uint32_t *cellStart, *cellStartRaw;

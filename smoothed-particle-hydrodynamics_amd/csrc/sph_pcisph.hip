@@ -29,6 +29,9 @@
 #define PD_BATCH 16  // predicted density: 16 B per neighbour
 #endif
 
+// index into SphDev::gatherRec: groups of four particles, [4 x part 0][4 x part 1] (one 128-byte line; see k_pack_gather_records)
+__device__ __forceinline__ size_t rec_index(int j, int part) { return ((size_t)(j >> 2) << 3) + (size_t)(part << 2) + (size_t)(j & 3); }
+
 // the 8 x (int4 ids, float4 dists) of particle `id`
 struct NbrTile {
   const int4* ids;
@@ -172,7 +175,6 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
   // Branch-free (see k_predict_density): per batch of FC_BATCH neighbours the map loads, then all gathers in flight together.
   // The map is read batch by batch (not all 32 entries up front) and the velocity gather takes 12 bytes: at 193 VGPRs the
   // kernel ran two waves per SIMD, too few to cover its gathers.
-  typedef float f3 __attribute__((ext_vector_type(3)));
 #pragma unroll 1  // (a real loop: unrolled, hipcc hoists the loads of all four batches to the top and needs ~190 VGPRs)
   for (int b = 0; b < 32 / FC_BATCH; b++) {
     int jj[FC_BATCH];
@@ -184,15 +186,12 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
       jj[4 * q] = jq.x; jj[4 * q + 1] = jq.y; jj[4 * q + 2] = jq.z; jj[4 * q + 3] = jq.w;
       rr[4 * q] = rq.x; rr[4 * q + 1] = rq.y; rr[4 * q + 2] = rq.z; rr[4 * q + 3] = rq.w;
     }
-    float4 xj[FC_BATCH];
-    f3 vj[FC_BATCH];
-    float rhoj[FC_BATCH];
+    float4 xj[FC_BATCH], vr[FC_BATCH];
 #pragma unroll
     for (int k = 0; k < FC_BATCH; k++) {
       const int jc = NBR_INDEX(jj[k]);
-      xj[k] = d.sortedPos[jc];
-      vj[k] = *reinterpret_cast<const f3*>(&d.sortedVel[jc]);  // for a boundary neighbour v is its wall normal (sphFluid.cl:653)
-      rhoj[k] = d.rho[jc];
+      xj[k] = d.gatherRec[rec_index(jc, 0)];
+      vr[k] = d.gatherRec[rec_index(jc, 1)];  // (v.xyz, rho); for a boundary neighbour v is its wall normal (sphFluid.cl:653)
     }
 #pragma unroll
     for (int k = 0; k < FC_BATCH; k++) {
@@ -201,11 +200,11 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
       if (valid && TYPE_OF(xj[k]) == SPH_BOUNDARY_PARTICLE) bnd |= 1u << slot;
       if (valid && TYPE_OF(xj[k]) == SPH_ELASTIC_PARTICLE) ela |= 1u << slot;
       const bool use = valid && rr[k] < d.hs;
-      const float rj = rhoj[k];
+      const float rj = vr[k].w;
       const float w = d.hs - rr[k];
-      sx = use ? sx + (vj[k].x - vi.x) * w / rj : sx;
-      sy = use ? sy + (vj[k].y - vi.y) * w / rj : sy;
-      sz = use ? sz + (vj[k].z - vi.z) * w / rj : sz;
+      sx = use ? sx + (vr[k].x - vi.x) * w / rj : sx;
+      sy = use ? sy + (vr[k].y - vi.y) * w / rj : sy;
+      sz = use ? sz + (vr[k].z - vi.z) * w / rj : sz;
       tx = use ? tx + d.surfTens * (xi.x - xj[k].x) : tx;
       ty = use ? ty + d.surfTens * (xi.y - xj[k].y) : ty;
       tz = use ? tz + d.surfTens * (xi.z - xj[k].z) : tz;
@@ -226,6 +225,20 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
   else { d.accP[id] = zero; d.rp[id].y = 0.f; }
 }
 
+// Gather records of the forces kernel: what it needs of a neighbour — (x, y, z, type) and (v.xyz, rho) — in ONE 128-byte line,
+// groups of four particles: [4 x (x,y,z,type)][4 x (vx,vy,vz,rho)]. A/B on MI355X at 16.5 M particles (tools/time_stage.py):
+// three gathers from three arrays (position, velocity, density) 2.06 ms; position and velocity in one line, density apart
+// 1.54 ms; everything in one line 1.22 ms + this pack pass (68 B per particle, 0.2 ms). A wave's gather instruction costs by
+// the number of different lines it touches. Kept out of k_density so that the roofline-graded pass moves exactly its 132 B.
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_pack_gather_records(SphDev d) {
+  const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (id >= d.N) return;
+  const float4 v = d.sortedVel[id];
+  d.gatherRec[rec_index(id, 0)] = d.sortedPos[id];
+  d.gatherRec[rec_index(id, 1)] = make_float4(v.x, v.y, v.z, d.rho[id]);
+}
+
 // Slab mode: forces are only needed on the owned layers, but every local particle needs what K7 does besides the
 // acceleration — the iteration-0 predicted position (pressure = 0 is implied by the first fused predictDensity).
 __global__ __launch_bounds__(SPH_BLOCK) void k_ghost_init(SphDev d) {
@@ -244,6 +257,7 @@ int sphk_ghost_init(sph_solver* s) {
 int sphk_forces(sph_solver* s, bool fusePredict, int ghostDepth) {
   const int nb = sph_blocks(s->d.N);
   const SphDev d = sph_ranged(s, ghostDepth);
+  hipLaunchKernelGGL(k_pack_gather_records, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d);
   if (fusePredict) hipLaunchKernelGGL((k_forces<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   else hipLaunchKernelGGL((k_forces<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   SPH_HIP(hipGetLastError());
@@ -446,7 +460,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
     float4 xj[PF_BATCH];
     float2 rpj[PF_BATCH];
 #pragma unroll
-    for (int k = 0; k < PF_BATCH; k++) { const int jc = NBR_INDEX(jj[k]); xj[k] = d.sortedPos[jc]; rpj[k] = d.rp[jc]; }
+    for (int k = 0; k < PF_BATCH; k++) {
+      const int jc = NBR_INDEX(jj[k]);
+      xj[k] = d.sortedPos[jc];
+      rpj[k] = d.rp[jc];
+    }
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const float r = rr[k];

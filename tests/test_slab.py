@@ -201,11 +201,14 @@ def test_particle_faster_than_one_layer_per_step_is_reported():
     n = cfg.particleCount
     lay = S.particle_layers(sc["position"], cfg)
     lo, hi = int(lay.min()), int(lay.max()) + 1
-    slab = S.make_slab([lo, (lo + hi) // 2, hi], 0, 2, n)
+    top = int(lay[sc["position"][:, 3].astype(int) == 1].max())  # highest liquid layer; the box above it is empty
+    assert top + 4 < hi
+    slab = S.make_slab([lo, top + 4, hi], 0, 2, n)  # rank 0 of 2: owns the liquid and three empty layers above it
     idx = S.local_indices(lay, slab)
     vel = sc["velocity"][idx].copy()
-    fast = int(np.flatnonzero((lay[idx] == lo + 3) & (sc["position"][idx, 3].astype(int) == 1))[0])
-    vel[fast, 2] = 4.0  # 4.0 * timeStep * simulationScaleInv = 9.9 units = 1.5 cell layers in one step
+    liquid = np.flatnonzero(sc["position"][idx, 3].astype(int) == 1)
+    fast = int(liquid[np.argmax(sc["position"][idx][liquid, 2])])  # on the free top face of the liquid block: nothing in its way
+    vel[fast, 2] = 6.0  # 6.0 * timeStep * simulationScaleInv = 14.8 units = 2.2 cell layers in one step
     be = S.HipSlabBackend(cfg, sc["position"][idx], vel, idx, slab)
     be.step(0)
     with pytest.raises(sphmi.SphError, match="more than one cell layer"):
