@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <cmath>
 #include <vector>
 
 #include "sph_common.h"
@@ -236,6 +237,21 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   if (cfg->maxIteration < 1) { sph_set_error("maxIteration must be >= 1"); return SPH_ERR_INVALID; }
   if (!(cfg->h > 0.f) || !(cfg->hashGridCellSize > 0.f)) { sph_set_error("h / hashGridCellSize must be positive"); return SPH_ERR_INVALID; }
 
+  // Input sanity the reference does not have. Non-finite coordinates make every particle hash into one cell (a quadratic
+  // search); in wide mode a coordinate outside the box gives a cell id outside [0, gridCellCount), and the radix sort only
+  // orders the bits a valid id can have. (Reference mode keeps the reference's behaviour for out-of-box input: ids alias.)
+  {
+    const bool wide = cfg->cellIdMask == 0xffffffffu;
+    for (int i = 0; i < N; i++) {
+      const float x = position[4 * (size_t)i], y = position[4 * (size_t)i + 1], z = position[4 * (size_t)i + 2];
+      const bool finite = std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
+      const bool inside = x >= cfg->xmin && x <= cfg->xmax && y >= cfg->ymin && y <= cfg->ymax && z >= cfg->zmin && z <= cfg->zmax;
+      if (!finite || (wide && !inside)) {
+        sph_set_error("particle %d at (%g, %g, %g) is %s", i, x, y, z, finite ? "outside the box (wide cell ids need in-box input)" : "not finite");
+        return SPH_ERR_INVALID;
+      }
+    }
+  }
   int ndev = 0;
   const hipError_t devErr = hipGetDeviceCount(&ndev);
   if (devErr != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {

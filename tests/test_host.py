@@ -207,6 +207,17 @@ def test_create_fails_loudly_without_gpu():
         scenes.hip_for(sc)
 
 
+def test_create_rejects_non_finite_and_out_of_box_input():
+    """sph_create validates before it touches the device: non-finite coordinates in any mode, out-of-box coordinates in wide mode
+    (the radix sort orders only the bits an in-grid cell id can have)."""
+    for mask, bad, what in ((0xffff, np.nan, "not finite"), (0xffffffff, -1.0, "outside the box"), (0xffffffff, np.inf, "not finite")):
+        sc = scenes.liquid_box((8.0, 8.0, 8.0), (6, 6, 6), mask=mask)
+        pos = sc["position"].copy()
+        pos[5, 1] = bad
+        with pytest.raises(sphmi.SphError, match=what):
+            sphmi.owHIPSolver(sc["cfg"], pos, sc["velocity"])
+
+
 def test_config_struct_layout_matches_header():
     """ctypes mirror of sph_config has the size the C compiler gives the header's struct."""
     import subprocess, tempfile
