@@ -281,21 +281,24 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   if (!xcd_range_id(d, id)) return;
   const float4 xi = d.predPos[id];
   const NbrTile t(d, id);
-  // Branch-free: per batch of PD_BATCH neighbours the id loads, then the gathers with an always-valid index (empty slots read
-  // record 0 and are masked out of the sum), so a wave keeps PD_BATCH gathers in flight instead of one per `if`. The batch loop
-  // is a real loop (see k_forces); the gathers take 12 bytes (the .w of a predicted position is not used).
+  // Branch-free: all 8 id loads first, then the gathers in batches of 8 with an always-valid index (empty slots read
+  // record 0 and are masked out of the sum), so a wave keeps 8 gathers in flight instead of one per `if`.
+  int4 j4[8];
+#pragma unroll
+  for (int g = 0; g < 8; g++) j4[g] = t.id4(g);
   double density = 0.0;
-#pragma unroll 1
+#pragma unroll
   for (int b = 0; b < 32 / PD_BATCH; b++) {
     int jj[PD_BATCH];
 #pragma unroll
-    for (int q = 0; q < PD_BATCH / 4; q++) {
-      const int4 jq = t.id4(b * (PD_BATCH / 4) + q);
-      jj[4 * q] = jq.x; jj[4 * q + 1] = jq.y; jj[4 * q + 2] = jq.z; jj[4 * q + 3] = jq.w;
+    for (int k = 0; k < PD_BATCH; k++) {
+      const int slot = b * PD_BATCH + k;
+      const int4 jq = j4[slot >> 2];
+      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
     }
-    f32x3 xj[PD_BATCH];
+    float4 xj[PD_BATCH];
 #pragma unroll
-    for (int k = 0; k < PD_BATCH; k++) xj[k] = *reinterpret_cast<const f32x3*>(&d.predPos[NBR_INDEX(jj[k])]);
+    for (int k = 0; k < PD_BATCH; k++) xj[k] = d.predPos[NBR_INDEX(jj[k])];
 #pragma unroll
     for (int k = 0; k < PD_BATCH; k++) {
       const float rx = xi.x - xj[k].x, ry = xi.y - xj[k].y, rz = xi.z - xj[k].z;
@@ -437,26 +440,30 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   const NbrTile t(d, id);
   float rx = 0.f, ry = 0.f, rz = 0.f;
   const float hq = d.hs * 0.25f;
-  // Branch-free, like k_predict_density: per batch of PF_BATCH neighbours the map loads, then the gathers with an always-valid
-  // index, masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`). The batch loop is a
-  // real loop (see k_forces) and the position gather takes 12 bytes.
-#pragma unroll 1
+  // Branch-free, like k_predict_density: map loads first, gathers in batches of PF_BATCH with an always-valid index,
+  // masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`).
+  int4 j4[8];
+  float4 r4[8];
+#pragma unroll
+  for (int g = 0; g < 8; g++) { j4[g] = t.id4(g); r4[g] = t.dist4(g); }
+#pragma unroll
   for (int b = 0; b < 32 / PF_BATCH; b++) {
     int jj[PF_BATCH];
     float rr[PF_BATCH];
 #pragma unroll
-    for (int q = 0; q < PF_BATCH / 4; q++) {
-      const int4 jq = t.id4(b * (PF_BATCH / 4) + q);
-      const float4 rq = t.dist4(b * (PF_BATCH / 4) + q);
-      jj[4 * q] = jq.x; jj[4 * q + 1] = jq.y; jj[4 * q + 2] = jq.z; jj[4 * q + 3] = jq.w;
-      rr[4 * q] = rq.x; rr[4 * q + 1] = rq.y; rr[4 * q + 2] = rq.z; rr[4 * q + 3] = rq.w;
+    for (int k = 0; k < PF_BATCH; k++) {
+      const int slot = b * PF_BATCH + k;
+      const int4 jq = j4[slot >> 2];
+      const float4 rq = r4[slot >> 2];
+      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
+      rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
     }
-    f32x3 xj[PF_BATCH];
+    float4 xj[PF_BATCH];
     float2 rpj[PF_BATCH];
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const int jc = NBR_INDEX(jj[k]);
-      xj[k] = *reinterpret_cast<const f32x3*>(&d.sortedPos[jc]);
+      xj[k] = d.sortedPos[jc];
       rpj[k] = d.rp[jc];
     }
 #pragma unroll
