@@ -588,10 +588,11 @@ extern "C" int sph_update_muscles(sph_solver* s, const float* signal, int n) {
   return SPH_OK;
 }
 
+static int check_finite_state(sph_solver* s);
+
 extern "C" int sph_synchronize(sph_solver* s) {
   ENTER(s);
-  SPH_HIP(hipStreamSynchronize(s->stream));
-  return SPH_OK;
+  return check_finite_state(s);  // (synchronises the stream)
 }
 
 // ---------------------------------------------------------------------------------------------- read-back
@@ -601,9 +602,21 @@ static int d2h(sph_solver* s, void* dst, const void* src, size_t bytes) {
   return SPH_OK;
 }
 
+// dbg[6]: particles with a non-finite coordinate seen by the hash kernel since the last check (the state has blown up)
+static int check_finite_state(sph_solver* s) {
+  uint32_t bad = 0;
+  SPH_HIP(hipMemcpyAsync(&bad, s->d.dbg + 6, sizeof(bad), hipMemcpyDeviceToHost, s->stream));
+  SPH_HIP(hipStreamSynchronize(s->stream));
+  if (!bad) return SPH_OK;
+  SPH_HIP(hipMemsetAsync(s->d.dbg + 6, 0, sizeof(uint32_t), s->stream));
+  sph_set_error("%u particle coordinate(s) are not finite: the simulation state has blown up", bad);
+  return SPH_ERR_INVALID;
+}
+
 extern "C" int sph_read_position(sph_solver* s, float* out) {
   ENTER(s); if (!out) return SPH_ERR_INVALID;
-  return d2h(s, out, s->d.posOrig, sizeof(float4) * (size_t)s->d.N);
+  const int rc = d2h(s, out, s->d.posOrig, sizeof(float4) * (size_t)s->d.N);
+  return rc != SPH_OK ? rc : check_finite_state(s);
 }
 extern "C" int sph_read_velocity(sph_solver* s, float* out) {
   ENTER(s); if (!out) return SPH_ERR_INVALID;

@@ -79,6 +79,9 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
 #ifndef FN_CAND_CAP
 #define FN_CAND_CAP 4096          // staged candidates per workgroup (SoA x/y/z: 48 KB; + lists 24 KB -> two workgroups per CU)
 #endif
+#ifndef FN_STAGE_PER
+#define FN_STAGE_PER 8           // candidate records per thread and staging round, all loads of a round in flight (A/B: 8 0.429, 12 0.440, 16 0.436 ms)
+#endif
 #define FN_WIN 16                 // cell-table window per row: covers batches that span up to 13 cells (else: direct table reads)
 #define FN_CAND_PAD 16            // the aligned, prefetching 4-wide walk reads (never uses) up to 15 slots past a piece
 #ifndef FN_LIST_CAP
@@ -158,6 +161,7 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, const FnArrays&
       c = min(max(c, 0), d.G - 1);              // no-op for particles inside the box; keeps the table read in range
       lo[k] = (int)g.cellStart[c];
       hi[k] = (int)g.cellStart[c + 1];
+      if (hi[k] - lo[k] > (1 << 20)) hi[k] = lo[k];  // a million particles in one cell: a blown-up state (counted by k_hash); do not walk it
       ldsBase[k] = -1;
 #ifndef FN_EXACT_GLOBAL
       if (r >= 0 && hi[k] > lo[k] && lo[k] >= sh.rowLo[r] && hi[k] <= sh.rowHi[r]) ldsBase[k] = sh.rowBase[r] + (lo[k] - sh.rowLo[r]);
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   if (tid >= 192 && tid < 256) sh.binU[tid - 192] = binU[tid - 192];
   FN_STAMP(0)
   {
-    constexpr int PER = FN_LANES == 4 ? 6 : 8;  // records per thread and round, all loads of a round in flight together
+    constexpr int PER = FN_LANES == 4 ? 6 : FN_STAGE_PER;  // records per thread and round, all loads of a round in flight together
 #pragma unroll 1
     for (int f0 = 0; f0 < total; f0 += PER * FN_THREADS) {
       float4 rec[PER];

@@ -8,6 +8,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_hash(SphDev d) {
   const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (id >= d.N) return;
   const float4 p = d.posOrig[id];
+  // A non-finite coordinate means the simulation has blown up; such particles all hash into one cell and the search turns
+  // quadratic. Counted here, reported by the next blocking call (sph_synchronize / sph_read_*) as SPH_ERR_INVALID.
+  if (!(fabsf(p.x) <= 3.0e38f && fabsf(p.y) <= 3.0e38f && fabsf(p.z) <= 3.0e38f)) atomicAdd(&d.dbg[6], 1u);
   // cellFactors ignores xmin/ymin/zmin (sphFluid.cl:197-199)
   const int cx = (int)(p.x * d.cellSizeInv), cy = (int)(p.y * d.cellSizeInv), cz = (int)(p.z * d.cellSizeInv);
   const int cell = cx + cy * d.gx + cz * d.gx * d.gy;
@@ -25,6 +28,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_hash_compact(SphDev d, CompactKey
   const int id = blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (id >= d.N) return;
   const float4 p = d.posOrig[id];
+  if (!(fabsf(p.x) <= 3.0e38f && fabsf(p.y) <= 3.0e38f && fabsf(p.z) <= 3.0e38f)) atomicAdd(&d.dbg[6], 1u);  // (see k_hash)
   const int cx = min(max((int)(p.x * d.cellSizeInv), 0), c.usedX - 1), cy = min(max((int)(p.y * d.cellSizeInv), 0), c.usedY - 1);
   const int cz = min(max((int)(p.z * d.cellSizeInv) - c.czBase, 0), c.layers - 1);
   d.keys[id] = (uint32_t)(cx + c.usedX * (cy + c.usedY * cz));

@@ -461,6 +461,22 @@ def test_coincident_particles_neighbour_search():
     assert (d == 0.0).sum() >= 10
 
 
+def test_blown_up_state_is_reported():
+    """Coincident particles make the reference divide by r = 0 (sphFluid.cl:1172-1178): their coordinates become NaN in the first
+    step. The next step's hash kernel counts non-finite coordinates and the next blocking call fails loudly instead of the caller
+    finding out from a search that has turned quadratic."""
+    sc = scenes.liquid_box((8.0, 8.0, 8.0), (12, 10, 12), jitter_in_r0=0.03)
+    pos = sc["position"].copy()
+    pos[5:10, :3] = pos[200:205, :3]
+    sc["position"] = pos
+    hip = scenes.hip_for(sc)
+    hip.step(0)
+    hip.synchronize()  # the NaNs exist now, but nothing has hashed them yet
+    hip.step(1)
+    with pytest.raises(sphmi.SphError, match="not finite"):
+        hip.synchronize()
+
+
 @pytest.mark.parametrize("iterations", [1, 2, 4])
 def test_other_predict_correct_iteration_counts(iterations):
     """maxIteration (owPhysicsConstant.h:76) is a run-time parameter here: the fused step must follow the oracle for
