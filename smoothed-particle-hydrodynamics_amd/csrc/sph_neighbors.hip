@@ -252,6 +252,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   const int p = tid >> FN_LOG_LANES, quadLane = tid & (FN_LANES - 1);  // quadLane: lane inside the particle's group
   const int pairB = FN_LANES == 4 ? quadLane >> 1 : quadLane, sub = FN_LANES == 4 ? (quadLane & 1) : 0;
   const int rangeBegin = (int)cellStart[d.rangeLo], rangeEnd = (int)cellStart[d.rangeHi];  // all particles, or fewer ghost layers
+  // (an XCD-aware tile order — each XCD one contiguous eighth of the tiles — was measured: 0.441 vs 0.430 ms on config #2, no change at 16.5 M)
   const int p0 = rangeBegin + blockIdx.x * FN_PART;
   if (p0 >= rangeEnd) return;  // uniform
   const int id = p0 + p;
