@@ -11,4 +11,4 @@ for path in sys.argv[1:]:
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel".ljust(42) + "".join(n[-18:].rjust(20) for n in names))
 for k in sorted(acc):
-    print(k.ljust(42) + "".join(("%.3g" % (sum(acc[k][n]) / len(acc[k][n])) if acc[k][n] else "-").rjust(20) for n in names))
+    print(k.ljust(42) + "".join(("%.6g" % (sum(acc[k][n]) / len(acc[k][n])) if acc[k][n] else "-").rjust(20) for n in names))
