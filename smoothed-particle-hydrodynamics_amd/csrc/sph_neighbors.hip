@@ -87,6 +87,9 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
 #ifndef FN_LIST_CAP
 #define FN_LIST_CAP (96 / FN_LANES)  // compaction list entries per lane (u16 [entry][lane]); 96 per particle
 #endif
+#ifndef FN_CHUNK
+#define FN_CHUNK 8                 // list entries per wave-uniform skip test in the replay loops (A/B: 8 0.419 ms, 4 0.445 ms)
+#endif
 #define FN_SLOTS_PER_LANE (SPH_MAXN / FN_LANES)  // map slots every lane of a particle finishes (square root + store)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -531,34 +534,34 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   float d2v[FN_LIST_CAP];
   uint32_t slotPk[FN_LIST_CAP / 2];
 #pragma unroll
-  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += FN_CHUNK) {
     if (__any(c0 < total)) {
-      int slotv[8];
+      int slotv[FN_CHUNK];
 #pragma unroll
-      for (int u = 0; u < 8; u++) slotv[u] = min((int)myList[c0 + u][lane], FN_CAND_CAP + FN_CAND_PAD - 1);
+      for (int u = 0; u < FN_CHUNK; u++) slotv[u] = min((int)myList[c0 + u][lane], FN_CAND_CAP + FN_CAND_PAD - 1);
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < FN_CHUNK; u++) {
         const int sl = slotv[u];
         const float ex = me.x - sh.x[sl], ey = me.y - sh.y[sl], ez = me.z - sh.z[sl];
         const float v = ex * ex + ey * ey + ez * ez;
         d2v[c0 + u] = (c0 + u < total) ? v : __builtin_inff();  // +inf never passes a `<` / `<=` test below
       }
 #pragma unroll
-      for (int u = 0; u < 8; u += 2) slotPk[(c0 + u) >> 1] = (uint32_t)slotv[u] | ((uint32_t)slotv[u + 1] << 16);
+      for (int u = 0; u < FN_CHUNK; u += 2) slotPk[(c0 + u) >> 1] = (uint32_t)slotv[u] | ((uint32_t)slotv[u + 1] << 16);
     } else {
 #pragma unroll
-      for (int u = 0; u < 8; u++) d2v[c0 + u] = __builtin_inff();
+      for (int u = 0; u < FN_CHUNK; u++) d2v[c0 + u] = __builtin_inff();
 #pragma unroll
-      for (int u = 0; u < 8; u += 2) slotPk[(c0 + u) >> 1] = 0u;
+      for (int u = 0; u < FN_CHUNK; u += 2) slotPk[(c0 + u) >> 1] = 0u;
     }
   }
   FN_STAMP(6)
   // ---- 2a. pass 0 + threshold (sphFluid.cl:157-161,310-323) without building the histogram: C(j) = number of hits in
   // bins 0..j = number of hits with d^2 < U[j] (U precomputed exactly on the host). The reference's loop stops at
   // j* = min{ j : C(j) >= 32 } with jb = j* if C(j*) == 32, j* - 1 if it overshoots, and jb = 30 if no such j exists.
-  int liveEnd = 8;  // wave-uniform: entries at or past it are +inf in every lane, and the counting loops skip them
+  int liveEnd = FN_CHUNK;  // wave-uniform: entries at or past it are +inf in every lane, and the counting loops skip them
 #pragma unroll
-  for (int c0 = 8; c0 < FN_LIST_CAP; c0 += 8) liveEnd = __any(c0 < total) ? c0 + 8 : liveEnd;
+  for (int c0 = FN_CHUNK; c0 < FN_LIST_CAP; c0 += FN_CHUNK) liveEnd = __any(c0 < total) ? c0 + FN_CHUNK : liveEnd;
   int lo = 0, hi = SPH_RSEG, cAtHi = 0;
 #pragma unroll 1
   for (int it = 0; it < 5; it++) {
@@ -566,10 +569,10 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
     const float U = sh.binU[min(mid, SPH_RSEG - 1)];
     int c = 0;
 #pragma unroll
-    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += FN_CHUNK) {
       if (c0 < liveEnd) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) c += (d2v[c0 + u] < U) ? 1 : 0;
+        for (int u = 0; u < FN_CHUNK; u++) c += (d2v[c0 + u] < U) ? 1 : 0;
       }
     }
     c += grp_other_half(c);
@@ -587,10 +590,10 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   // are dropped, which is what the reference's `break` / `spaceLeft` logic amounts to (sphFluid.cl:145,168-169).
   fn_mask_t acc = 0;
 #pragma unroll
-  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+  for (int c0 = 0; c0 < FN_LIST_CAP; c0 += FN_CHUNK) {
     if (c0 < liveEnd) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc |= (d2v[c0 + u] <= r2) ? ((fn_mask_t)1 << (c0 + u)) : (fn_mask_t)0;
+      for (int u = 0; u < FN_CHUNK; u++) acc |= (d2v[c0 + u] <= r2) ? ((fn_mask_t)1 << (c0 + u)) : (fn_mask_t)0;
     }
   }
   fn_mask_t below[4];  // bits of the entries before the end of piece i
@@ -628,10 +631,10 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
     // walk the entries in list order with a running (piece start, index delta, rank inside the piece)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
 #pragma unroll
-    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += 8) {
+    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += FN_CHUNK) {
       if (!__any(c0 < total)) continue;  // wave-uniform skip of empty chunks
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < FN_CHUNK; u++) {
         const int e = c0 + u;
         if (e == segEnd[0]) { curStart = start[1]; curDelta = absDelta[1]; rank = 0; }  // (empty pieces cascade in order)
         if (e == segEnd[1]) { curStart = start[2]; curDelta = absDelta[2]; rank = 0; }
