@@ -58,7 +58,13 @@ __device__ __forceinline__ bool xcd_range_id(const SphDev& d, int& id) {
   if (b >= active) return false;
 #ifndef NO_XCD_REMAP
   const int per = active >> 3, even = per << 3;
-  if (b < even) b = (b & 7) * per + (b >> 3);
+  if (b < even) {
+    const int x = b & 7;
+    int k = b >> 3;  // k-th workgroup dealt to XCD x
+    // (a CU-local sub-order inside the XCD — every CU a contiguous sub-range, hoping its resident workgroups share L1 lines — was
+    // measured: 0-7 % slower on all three gather kernels)
+    b = x * per + k;
+  }
 #endif
   id = begin + b * SPH_BLOCK + threadIdx.x;
   return id < end;

@@ -21,4 +21,4 @@ st = h.stage_times(); c = h.buffer("debugCounters")
 N = sc["cfg"].particleCount
 print(name, "N", N, "ms/step %.3f" % (dt * 1e3 / steps), "particle-steps/s %.3e" % (N * steps / dt))
 print({k: round(ms / steps, 4) for k, (ms, n) in st.items() if n})
-print("fallback particles per step: unstaged %d, list overflow %d" % (c[0] // steps, c[1] // steps))
+print("particles per step left to the in-kernel exact walk: unstaged %d, list overflow %d" % (c[0] // steps, c[1] // steps))
