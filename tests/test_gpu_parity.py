@@ -572,3 +572,26 @@ def test_cpp_driver_generated_worm_scene_matches_reference_fixture(tmp_path):
     pos = np.fromfile(out, np.float32).reshape(-1, 4)
     assert pos.shape[0] == 232887
     assert scenes.bits_equal(pos[z["sample_ids"]], z["position_sample_9"])
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads (a tiny workload here; the default is config #4)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                        "--cpu-steps", "2", "--no-extra"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "stages_ms", "stages_frac"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "strong" and d["config"]["workload"] == "tiny" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert abs(d["value"] - d["config"]["particles"] * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["bytes_per_launch"] == d["config"]["particles"] * 132
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "particle-steps/s"
