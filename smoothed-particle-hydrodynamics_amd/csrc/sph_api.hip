@@ -240,6 +240,8 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   // Input sanity the reference does not have. Non-finite coordinates make every particle hash into one cell (a quadratic
   // search); in wide mode a coordinate outside the box gives a cell id outside [0, gridCellCount), and the radix sort only
   // orders the bits a valid id can have. (Reference mode keeps the reference's behaviour for out-of-box input: ids alias.)
+  // Creation is the only way in for such coordinates: integrate clamps every new position into the box (sphFluid.cl:1750-1755,
+  // integrate_particle), and a NaN — which no clamp catches — is counted by the hash kernel (dbg[6], check_finite_state).
   {
     const bool wide = cfg->cellIdMask == 0xffffffffu;
     for (int i = 0; i < N; i++) {
