@@ -209,16 +209,9 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
       const bool use = valid && rr[k] < d.hs;
       const float rj = vr[k].w;
       const float w = d.hs - rr[k];
-#ifdef DIAG_SHARED_RCP
-      const float rjinv = 1.f / rj;
-      sx = use ? sx + (vr[k].x - vi.x) * w * rjinv : sx;
-      sy = use ? sy + (vr[k].y - vi.y) * w * rjinv : sy;
-      sz = use ? sz + (vr[k].z - vi.z) * w * rjinv : sz;
-#else
       sx = use ? sx + (vr[k].x - vi.x) * w / rj : sx;
       sy = use ? sy + (vr[k].y - vi.y) * w / rj : sy;
       sz = use ? sz + (vr[k].z - vi.z) * w / rj : sz;
-#endif
       tx = use ? tx + d.surfTens * (xi.x - xj[k].x) : tx;
       ty = use ? ty + d.surfTens * (xi.y - xj[k].y) : ty;
       tz = use ? tz + d.surfTens * (xi.z - xj[k].z) : tz;
@@ -488,16 +481,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
       const float value = num / rpj[k].x;
       const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
       const bool use = jj[k] != -1 && r < d.hs;
-#ifdef DIAG_SHARED_RCP  // timing only (results differ in the last bit): upper bound of what sharing the denominator work could give
-      const float rinv = 1.f / r;
-      rx = use ? rx + value * vx * rinv : rx;
-      ry = use ? ry + value * vy * rinv : ry;
-      rz = use ? rz + value * vz * rinv : rz;
-#else
       rx = use ? rx + value * vx / r : rx;
       ry = use ? ry + value * vy / r : ry;
       rz = use ? rz + value * vz / r : rz;
-#endif
     }
   }
   const float scale = (float)(d.massGradW / (double)rpi.x);
