@@ -325,7 +325,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
   A(d.nbrId, mapN); A(d.nbrDist, mapN);
   A(d.rho, n);
-  A(s->blockHist, (size_t)256 * s->maxSortBlocks + 256);  // [256][maxSortBlocks] block histograms + 256 digit totals
+  A(s->blockHist, (size_t)SPH_SORT_MAX_DIGITS * s->maxSortBlocks + SPH_SORT_MAX_DIGITS);  // block histograms + digit totals
   A(d.gid, n); A(d.owned, n); A(s->slabCounts, 12);
   A(d.dbg, SPH_DBG_WORDS);
   float* binU = nullptr;
@@ -519,9 +519,18 @@ static int enqueue_step(sph_solver* s, const StepTail* tail) {
     RUN(SPH_ST_SORT, sphk_hash_sort_post_slab(s));
     RUN(SPH_ST_SORT_POST, sphk_index_fixed(s));
   } else {
-    RUN(SPH_ST_HASH, sphk_hash(s));
-    RUN(SPH_ST_SORT, sphk_sort(s));
-    RUN(SPH_ST_SORT_POST, sphk_sort_post_and_index(s));
+    int bits = s->sortBits;
+    bool compact = false;  // wide cell ids: only ~1/8 of the declared index space is reachable, which can save a radix pass
+    RUN(SPH_ST_HASH, sphk_hash_for_step(s, &bits, &compact));
+    RUN(SPH_ST_SORT, sphk_sort_pairs(s, s->d.N, bits));
+    if (compact) {
+      StageTimer t_(s, SPH_ST_SORT_POST);
+      rc = sphk_sort_post_rekey(s);
+      if (rc == SPH_OK) rc = sphk_index_fixed(s);
+      if (rc != SPH_OK) return rc;
+    } else {
+      RUN(SPH_ST_SORT_POST, sphk_sort_post_and_index(s));
+    }
   }
   // Slab mode: a stage runs only on the ghost layers its results are needed on (owned layers + depth layers per side).
   // Information travels one neighbour hop (<= 31h/30, i.e. 31/60 of a 2h cell layer) per stage, backwards from the owned

@@ -22,6 +22,7 @@
 #define SPH_MAXN 32
 #define SPH_RSEG 30  // radius_segments, sphFluid.cl:116
 #define SPH_DBG_WORDS 32  // diagnostic counters (SphDev::dbg)
+#define SPH_SORT_MAX_DIGITS 512   // radix digits per pass: 256 (8 bits) or 512 (9 bits)
 
 struct SphDev {  // what the kernels see; passed by value
   int N, G;
@@ -83,7 +84,7 @@ struct sph_solver {
   int slabCapRecords;        // frame capacity given to sph_slab_step_begin
   int slabKept;              // host copy of the kept count of the last sph_slab_pack (-1: none pending)
   // radix-sort workspace
-  uint32_t* blockHist;       // [256][maxSortBlocks] block histograms + 256 digit totals
+  uint32_t* blockHist;       // [SPH_SORT_MAX_DIGITS][maxSortBlocks] block histograms + SPH_SORT_MAX_DIGITS digit totals
   int maxSortBlocks;
   // stage progress for SPH_ERR_ORDER checks
   int progress;
@@ -134,6 +135,9 @@ __host__ __device__ static inline size_t nbr_index(int id, int slot) {
 int sphk_hash(sph_solver* s);
 int sphk_sort(sph_solver* s);
 int sphk_sort_pairs(sph_solver* s, int n, int bits);  // stable LSD sort of (keys, vals)[0..n) by the low `bits` of keys
+int sph_sort_passes(int bits);                         // radix passes sphk_sort_pairs takes for `bits` key bits (8- or 9-bit digits)
+int sphk_hash_for_step(sph_solver* s, int* sortBits, bool* compact);  // fused step: hash with compacted keys where that saves a pass
+int sphk_sort_post_rekey(sph_solver* s);               // the gather after a sort of compacted keys (puts the real cell ids back)
 int sphk_sort_post(sph_solver* s);        // gather + backIndex (K3)
 int sphk_index_raw(sph_solver* s);        // K4 table with -1 for empty cells
 int sphk_index_fixed(sph_solver* s);      // H2 table (cellStart)

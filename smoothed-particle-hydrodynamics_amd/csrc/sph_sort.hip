@@ -49,28 +49,49 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_sort_post_rekey(SphDev d) {
 
 static int bits_for(long long n) { int b = 1; while ((1LL << b) < n) b++; return b; }
 
-// hash + sort + gather of the fused step in slab mode; falls back to the plain path when the compaction does not apply
-int sphk_hash_sort_post_slab(sph_solver* s) {
+// The compaction of the current domain (the slab's layers in slab mode, the whole box otherwise) and the bits its keys need.
+static CompactKey compact_plan(const sph_solver* s, int* bits) {
   const SphDev& d = s->d;
   CompactKey c;
   c.usedX = min((int)(d.xmax * d.cellSizeInv) + 1, d.gx);
   c.usedY = min((int)(d.ymax * d.cellSizeInv) + 1, d.gy);
-  const long long lo = max((long long)s->slab.layerLo - s->slab.ghostLayers - 2, 0LL);
-  const long long hi = min((long long)s->slab.layerHi + s->slab.ghostLayers + 2, (long long)d.gz);
-  c.czBase = (int)lo; c.layers = (int)max(hi - lo, 1LL);
-  const long long cells = (long long)c.usedX * c.usedY * c.layers;
-  const int bits = bits_for(cells);
-  if (bits >= s->sortBits) {  // nothing to gain
-    int rc = sphk_hash(s);
-    if (rc == SPH_OK) rc = sphk_sort(s);
-    return rc == SPH_OK ? sphk_sort_post(s) : rc;
+  long long lo = 0, hi = min((long long)(d.zmax * d.cellSizeInv) + 1, (long long)d.gz);
+  if (s->hasSlab) {
+    lo = max((long long)s->slab.layerLo - s->slab.ghostLayers - 2, 0LL);
+    hi = min((long long)s->slab.layerHi + s->slab.ghostLayers + 2, (long long)d.gz);
   }
-  hipLaunchKernelGGL(k_hash_compact, dim3(sph_blocks(d.N)), dim3(SPH_BLOCK), 0, s->stream, d, c);
-  int rc = sphk_sort_pairs(s, d.N, bits);
-  if (rc != SPH_OK) return rc;
+  c.czBase = (int)lo; c.layers = (int)max(hi - lo, 1LL);
+  *bits = bits_for((long long)c.usedX * c.usedY * c.layers);
+  return c;
+}
+
+// K2 of the fused step. Wide cell ids only (the reference's 16-bit ids alias, so no monotone compaction exists), and only
+// when the compacted keys take fewer radix passes than the real ones.
+int sphk_hash_for_step(sph_solver* s, int* sortBits, bool* compact) {
+  int bits = s->sortBits;
+  const CompactKey c = compact_plan(s, &bits);
+  *compact = s->d.cellMask == 0xffffffffu && sph_sort_passes(bits) < sph_sort_passes(s->sortBits);
+  *sortBits = *compact ? bits : s->sortBits;
+  if (!*compact) return sphk_hash(s);
+  hipLaunchKernelGGL(k_hash_compact, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d, c);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
+}
+
+int sphk_sort_post_rekey(sph_solver* s) {
   hipLaunchKernelGGL(k_sort_post_rekey, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
+}
+
+// hash + sort + gather of the fused step in slab mode
+int sphk_hash_sort_post_slab(sph_solver* s) {
+  int bits;
+  bool compact;
+  int rc = sphk_hash_for_step(s, &bits, &compact);
+  if (rc == SPH_OK) rc = sphk_sort_pairs(s, s->d.N, bits);
+  if (rc != SPH_OK) return rc;
+  return compact ? sphk_sort_post_rekey(s) : sphk_sort_post(s);
 }
 
 int sphk_hash(sph_solver* s) {
@@ -79,32 +100,36 @@ int sphk_hash(sph_solver* s) {
   return SPH_OK;
 }
 
-// ------------------------------------------------------------------ stable LSD radix sort, 8 bits per pass
+// ------------------------------------------------------------------ stable LSD radix sort, 8 or 9 bits per pass
 // Tile = 256 threads x 16 keys. Wave w of a block owns the contiguous 1024 keys [w*1024, (w+1)*1024) of the tile and
 // walks them in 16 rounds of 64, so "earlier in memory" == (block, wave, round, lane) order and ranks stay stable:
 // myCompare orders by cell only and glibc's qsort keeps ties in input (= ascending orig id) order.
+// BITS = 9 (512 digits) is used when it saves a pass: 17-18 key bits take 2 passes instead of 3 (the compacted cell ids of
+// the 16.5 M box need 18), 25-27 bits 3 instead of 4.
 #define RS_ITEMS 16
 #define RS_TILE (SPH_BLOCK * RS_ITEMS)
 
+template <int BITS>
 __global__ __launch_bounds__(SPH_BLOCK) void k_radix_hist(const uint32_t* __restrict__ keys, int N, int shift,
                                                            uint32_t* __restrict__ blockHist, int numBlocks) {
-  __shared__ uint32_t hist[256];
-  hist[threadIdx.x] = 0;
+  constexpr int D = 1 << BITS;
+  __shared__ uint32_t hist[D];
+  for (int i = threadIdx.x; i < D; i += SPH_BLOCK) hist[i] = 0;
   __syncthreads();
   const int base = blockIdx.x * RS_TILE;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const int i = base + r * SPH_BLOCK + threadIdx.x;
-    if (i < N) atomicAdd(&hist[(keys[i] >> shift) & 255u], 1u);
+    if (i < N) atomicAdd(&hist[(keys[i] >> shift) & (uint32_t)(D - 1)], 1u);
   }
   __syncthreads();
-  blockHist[(size_t)threadIdx.x * numBlocks + blockIdx.x] = hist[threadIdx.x];
+  for (int i = threadIdx.x; i < D; i += SPH_BLOCK) blockHist[(size_t)i * numBlocks + blockIdx.x] = hist[i];
 }
 
 // Offsets in two levels, no single-block pass over the whole table:
 //   k_radix_scan_rows: one workgroup per digit turns that digit's row blockHist[digit][0..numBlocks) into an exclusive
 //                      scan in place and leaves the row total in digitTotal[digit];
-//   k_radix_scatter:   every workgroup scans the 256 digit totals itself (LDS) to get the digit bases.
+//   k_radix_scatter:   every workgroup scans the digit totals itself (LDS) to get the digit bases.
 __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scan_rows(uint32_t* __restrict__ blockHist, int numBlocks,
                                                                 uint32_t* __restrict__ digitTotal) {
   __shared__ uint32_t part[SPH_BLOCK];
@@ -126,27 +151,36 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scan_rows(uint32_t* __restr
   if (threadIdx.x == SPH_BLOCK - 1) digitTotal[blockIdx.x] = part[SPH_BLOCK - 1];
 }
 
+template <int BITS>
 __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __restrict__ keysIn,
                                                               const uint32_t* __restrict__ valsIn,
                                                               uint32_t* __restrict__ keysOut,
                                                               uint32_t* __restrict__ valsOut, int N, int shift,
                                                               const uint32_t* __restrict__ blockHist, int numBlocks,
                                                               const uint32_t* __restrict__ digitTotal) {
-  __shared__ volatile uint32_t waveCount[4][256];  // running count of digit d inside wave w's range
-  __shared__ uint32_t digitBase[4][256];           // global output index of the first key with digit d of wave w
-  __shared__ uint32_t scan[256];
+  constexpr int D = 1 << BITS, PER = D / SPH_BLOCK;  // digits, digits per thread in the per-digit steps
+  __shared__ volatile uint32_t waveCount[4][D];  // running count of digit d inside wave w's range
+  __shared__ uint32_t digitBase[4][D];           // global output index of the first key with digit d of wave w
+  __shared__ uint32_t scan[SPH_BLOCK];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 4 * 256; i += SPH_BLOCK) waveCount[i >> 8][i & 255] = 0;
-  const uint32_t myTotal = digitTotal[threadIdx.x];
-  scan[threadIdx.x] = myTotal;
+  for (int i = threadIdx.x; i < 4 * D; i += SPH_BLOCK) waveCount[i / D][i % D] = 0;
+  uint32_t tot[PER], mySum = 0;  // thread t owns the digits t*PER .. t*PER + PER-1
+#pragma unroll
+  for (int p = 0; p < PER; p++) { tot[p] = digitTotal[threadIdx.x * PER + p]; mySum += tot[p]; }
+  scan[threadIdx.x] = mySum;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the 256 digit totals
+  for (int off = 1; off < SPH_BLOCK; off <<= 1) {  // inclusive scan of the per-thread sums of the digit totals
     const uint32_t v = (threadIdx.x >= (unsigned)off) ? scan[threadIdx.x - off] : 0u;
     __syncthreads();
     scan[threadIdx.x] += v;
     __syncthreads();
   }
-  const uint32_t digitStart = scan[threadIdx.x] - myTotal;  // keys with a smaller digit, whole array
+  uint32_t digitStart[PER];  // keys with a smaller digit, whole array
+  {
+    uint32_t run = scan[threadIdx.x] - mySum;
+#pragma unroll
+    for (int p = 0; p < PER; p++) { digitStart[p] = run; run += tot[p]; }
+  }
   const int base = blockIdx.x * RS_TILE + wave * (64 * RS_ITEMS);
   const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
@@ -156,10 +190,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __r
     const bool valid = i < N;
     key[r] = valid ? keysIn[i] : 0u;
     val[r] = valid ? valsIn[i] : 0u;
-    const uint32_t dgt = (key[r] >> shift) & 255u;
+    const uint32_t dgt = (key[r] >> shift) & (uint32_t)(D - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < BITS; b++) {
       const bool bit = (dgt >> b) & 1u;
       const unsigned long long m = __ballot(valid && bit);
       peers &= bit ? m : ~m;
@@ -170,9 +204,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __r
     if (valid && (peers & ltMask) == 0ull) waveCount[wave][dgt] = before + (uint32_t)__popcll(peers);
   }
   __syncthreads();
-  {
-    const int dgt = threadIdx.x;  // one thread per digit
-    uint32_t run = digitStart + blockHist[(size_t)dgt * numBlocks + blockIdx.x];
+#pragma unroll
+  for (int p = 0; p < PER; p++) {
+    const int dgt = threadIdx.x * PER + p;
+    uint32_t run = digitStart[p] + blockHist[(size_t)dgt * numBlocks + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < 4; w++) { digitBase[w][dgt] = run; run += waveCount[w][dgt]; }
   }
@@ -181,7 +216,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __r
   for (int r = 0; r < RS_ITEMS; r++) {
     const int i = base + r * 64 + lane;
     if (i < N) {
-      const uint32_t dst = digitBase[wave][(key[r] >> shift) & 255u] + rank[r];
+      const uint32_t dst = digitBase[wave][(key[r] >> shift) & (uint32_t)(D - 1)] + rank[r];
       keysOut[dst] = key[r];
       valsOut[dst] = val[r];
     }
@@ -190,18 +225,30 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_radix_scatter(const uint32_t* __r
 
 int sphk_sort(sph_solver* s) { return sphk_sort_pairs(s, s->d.N, s->sortBits); }
 
-int sphk_sort_pairs(sph_solver* s, int n, int bits) {
+// passes needed for `bits` key bits with the cheaper digit width (9 bits only when that saves a pass)
+int sph_sort_digit_bits(int bits) { return ((bits + 8) / 9 < (bits + 7) / 8) ? 9 : 8; }
+int sph_sort_passes(int bits) { const int w = sph_sort_digit_bits(bits); return (bits + w - 1) / w; }
+
+template <int BITS>
+static void radix_pass(sph_solver* s, int n, int nb, int shift) {
   SphDev& d = s->d;
+  constexpr int D = 1 << BITS;
+  uint32_t* digitTotal = s->blockHist + (size_t)SPH_SORT_MAX_DIGITS * s->maxSortBlocks;
+  hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, n, shift, s->blockHist, nb);
+  hipLaunchKernelGGL(k_radix_scan_rows, dim3(D), dim3(SPH_BLOCK), 0, s->stream, s->blockHist, nb, digitTotal);
+  hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.vals, d.keysAlt, d.valsAlt,
+                     n, shift, s->blockHist, nb, digitTotal);
+  uint32_t* t = d.keys; d.keys = d.keysAlt; d.keysAlt = t;
+  t = d.vals; d.vals = d.valsAlt; d.valsAlt = t;
+}
+
+int sphk_sort_pairs(sph_solver* s, int n, int bits) {
   const int nb = (n + RS_TILE - 1) / RS_TILE;
   if (nb > s->maxSortBlocks) { sph_set_error("sort of %d keys exceeds the solver's capacity", n); return SPH_ERR_SIZE; }
-  for (int shift = 0; shift < bits; shift += 8) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, n, shift, s->blockHist, nb);
-    uint32_t* digitTotal = s->blockHist + (size_t)256 * s->maxSortBlocks;
-    hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(SPH_BLOCK), 0, s->stream, s->blockHist, nb, digitTotal);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d.keys, d.vals, d.keysAlt, d.valsAlt,
-                       n, shift, s->blockHist, nb, digitTotal);
-    uint32_t* t = d.keys; d.keys = d.keysAlt; d.keysAlt = t;
-    t = d.vals; d.vals = d.valsAlt; d.valsAlt = t;
+  const int w = sph_sort_digit_bits(bits);
+  for (int shift = 0; shift < bits; shift += w) {
+    if (w == 9) radix_pass<9>(s, n, nb, shift);
+    else radix_pass<8>(s, n, nb, shift);
   }
   SPH_HIP(hipGetLastError());
   return SPH_OK;

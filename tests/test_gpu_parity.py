@@ -506,6 +506,19 @@ def test_random_heterogeneous_scenes_against_oracle(seed):
             assert_same(canon_hip(hip, N), canon_ora(ora, N), "random scene %d step %d" % (seed, it), FUSED_SKIP)
 
 
+def test_compacted_keys_and_nine_bit_radix_digits():
+    """Wide cell ids, a box whose reachable cells (42 x 41 x 43 = 74 k) need 17 key bits while the declared grid needs 20: the
+    fused step sorts compacted keys in two passes of 9-bit digits instead of three of 8 (sph_sort.hip) and puts the real cell
+    ids back afterwards. Permutation, cell ids, cell table and everything downstream must equal the oracle's."""
+    sc = scenes.liquid_box((82.0, 80.0, 84.0), (30, 20, 30), mask=0xffffffff, jitter_in_r0=0.2, origin_in_r0=(40.0, 30.0, 50.0))
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16)
+    for it in range(2):
+        hip.step(it)
+        ora.step()
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "compacted keys, step %d" % it, FUSED_SKIP)
+
+
 def test_blown_up_state_is_reported():
     """Coincident particles make the reference divide by r = 0 (sphFluid.cl:1172-1178): their coordinates become NaN in the first
     step. The next step's hash kernel counts non-finite coordinates and the next blocking call fails loudly instead of the caller
