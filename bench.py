@@ -47,7 +47,8 @@ DEFAULT_WORKLOAD = "config4_16M_box"
 # 3 predict-correct iterations). sort = 3 radix passes of wide ids x (8 R hist + 8 R + 8 W scatter); find_neighbors 268;
 # density 132; forces ~300 (+32 for the (v, rho) pack); predict_density 3 x 152 (correctPressure fused);
 # pressure_force 2 x (288 + 48 predictPositions) + (288 + 200 integrate).
-STAGE_ALGO_BYTES = {"hash": 20, "sort": 72, "sort_post": 69, "find_neighbors": 268, "density": 132, "forces": 332,
+STAGE_ALGO_BYTES = {"hash": 20, "sort": 72,  # (sort: 24 B per radix pass, set from the solver's pass count below)
+                    "sort_post": 69, "find_neighbors": 268, "density": 132, "forces": 332,
                     "predict_density": 456, "pressure_force": 1160}
 
 
@@ -180,7 +181,7 @@ def main():
     value = N * args.steps / wall  # N = particles of the whole job (all ranks)
 
     # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
-    stages_ms, stages_frac, roofline = {}, {}, None
+    stages_ms, stages_frac, roofline, sort_passes = {}, {}, None, None
     if not args.no_stage_pass:
         solver.set_stage_timing(True)
         solver.reset_stage_times()
@@ -210,8 +211,10 @@ def main():
                 if roofline["traffic"] is not None:
                     roofline["traffic_source"] = "profiles/density_traffic.json (committed rocprofv3 PMC passes; not this run)"
         # per stage: algorithmic bytes of all its launches in one step / its time / 8 TB/s (pure-liquid scenes)
-        stages_frac = {k: round(n_local * STAGE_ALGO_BYTES[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                       for k, v in stages_ms.items() if k in STAGE_ALGO_BYTES and v > 0}
+        sort_passes = solver.step_sort_passes()
+        algo = dict(STAGE_ALGO_BYTES, sort=24 * sort_passes)  # 24 B per particle and radix pass (2 or 3 passes)
+        stages_frac = {k: round(n_local * algo[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                       for k, v in stages_ms.items() if k in algo and v > 0}
         step_ms = sum(stages_ms.values())
         if step_ms > 0:
             stages_frac["whole_step_2600B"] = round(n_local * 2600.0 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -335,6 +338,7 @@ def main():
             "ms_per_step_p50": None if p50_ms is None else round(p50_ms, 4),
             "ms_per_step_with_position_readback": None if readback_ms is None else round(readback_ms, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms, "stages_frac": stages_frac,
+            "radix_sort_passes": sort_passes,
         }
         if extra:
             out["config2_1M_cube"] = extra

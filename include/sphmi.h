@@ -136,6 +136,8 @@ typedef enum sph_stage {
 int sph_set_stage_timing(sph_solver* s, int enable);
 int sph_get_stage_times(sph_solver* s, double* ms_total, int64_t* launches, int n); /* n = SPH_ST_COUNT */
 int sph_reset_stage_times(sph_solver* s);
+/* Radix passes (8- or 9-bit digits) the sort of sph_step() takes for this solver: 24 algorithmic bytes per particle each. */
+int sph_step_sort_passes(sph_solver* s);
 
 /* ---- Spatial decomposition (no reference counterpart: the reference is single-device) -----------------
  * The global box is cut into z-slabs of whole cell layers, one solver (one GPU, one process) per slab. A solver holds the

@@ -601,6 +601,12 @@ extern "C" int sph_update_muscles(sph_solver* s, const float* signal, int n) {
 
 static int check_finite_state(sph_solver* s);
 
+extern "C" int sph_step_sort_passes(sph_solver* s) {
+  ENTER(s);
+  bool compact;
+  return sph_sort_passes(sphk_step_sort_bits(s, &compact));
+}
+
 extern "C" int sph_synchronize(sph_solver* s) {
   ENTER(s);
   return check_finite_state(s);  // (synchronises the stream)

@@ -136,6 +136,7 @@ int sphk_hash(sph_solver* s);
 int sphk_sort(sph_solver* s);
 int sphk_sort_pairs(sph_solver* s, int n, int bits);  // stable LSD sort of (keys, vals)[0..n) by the low `bits` of keys
 int sph_sort_passes(int bits);                         // radix passes sphk_sort_pairs takes for `bits` key bits (8- or 9-bit digits)
+int sphk_step_sort_bits(const sph_solver* s, bool* compact);         // key bits the fused step sorts (compacted keys or the real ones)
 int sphk_hash_for_step(sph_solver* s, int* sortBits, bool* compact);  // fused step: hash with compacted keys where that saves a pass
 int sphk_sort_post_rekey(sph_solver* s);               // the gather after a sort of compacted keys (puts the real cell ids back)
 int sphk_sort_post(sph_solver* s);        // gather + backIndex (K3)

@@ -67,12 +67,18 @@ static CompactKey compact_plan(const sph_solver* s, int* bits) {
 
 // K2 of the fused step. Wide cell ids only (the reference's 16-bit ids alias, so no monotone compaction exists), and only
 // when the compacted keys take fewer radix passes than the real ones.
-int sphk_hash_for_step(sph_solver* s, int* sortBits, bool* compact) {
+int sphk_step_sort_bits(const sph_solver* s, bool* compact) {
   int bits = s->sortBits;
-  const CompactKey c = compact_plan(s, &bits);
+  compact_plan(s, &bits);
   *compact = s->d.cellMask == 0xffffffffu && sph_sort_passes(bits) < sph_sort_passes(s->sortBits);
-  *sortBits = *compact ? bits : s->sortBits;
+  return *compact ? bits : s->sortBits;
+}
+
+int sphk_hash_for_step(sph_solver* s, int* sortBits, bool* compact) {
+  *sortBits = sphk_step_sort_bits(s, compact);
   if (!*compact) return sphk_hash(s);
+  int bits;
+  const CompactKey c = compact_plan(s, &bits);
   hipLaunchKernelGGL(k_hash_compact, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d, c);
   SPH_HIP(hipGetLastError());
   return SPH_OK;

@@ -90,7 +90,7 @@ _STAGE_FUNCS = ["sph_run_clear_buffers", "sph_run_hash_particles", "sph_run_sort
 EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sph_step", "sph_update_muscles",
                     "sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index",
                     "sph_read_buffer", "sph_read_neighbor_rows", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
-                    "sph_reset_stage_times", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed", "sph_slab_step_begin", "sph_slab_step_messages",
+                    "sph_reset_stage_times", "sph_step_sort_passes", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed", "sph_slab_step_begin", "sph_slab_step_messages",
                     "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
@@ -140,7 +140,7 @@ def device_lib():
         L.sph_create.argtypes = [C.POINTER(SphConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_void_p)]
         L.sph_destroy.argtypes = [C.c_void_p]
-        for f in _STAGE_FUNCS + ["sph_synchronize", "sph_reset_stage_times"]:
+        for f in _STAGE_FUNCS + ["sph_synchronize", "sph_reset_stage_times", "sph_step_sort_passes"]:
             getattr(L, f).argtypes = [C.c_void_p]
         L.sph_run_pcisph_integrate.argtypes = [C.c_void_p, C.c_int]
         L.sph_step.argtypes = [C.c_void_p, C.c_int]
@@ -449,6 +449,13 @@ class owHIPSolver:
 
     def reset_stage_times(self):
         return self._chk(self._L.sph_reset_stage_times(self._h))
+
+    def step_sort_passes(self):
+        """Radix passes the sort of the fused step takes for this solver (24 algorithmic bytes per particle each)."""
+        n = self._L.sph_step_sort_passes(self._h)
+        if n < 0:
+            self._chk(n)
+        return n
 
     def stage_times(self):
         n = len(STAGE_NAMES)
