@@ -25,6 +25,10 @@ def scene():
     sc = _scene()
     if os.environ.get("SPHMI_TEST_MAXITER"):  # other predict-correct iteration counts change every stage's ghost depth
         sc["cfg"].maxIteration = int(os.environ["SPHMI_TEST_MAXITER"])
+    if os.environ.get("SPHMI_TEST_FUZZ_SEED"):  # every liquid particle its own velocity, up to 0.37 cell layers per step along z
+        rng = np.random.default_rng(int(os.environ["SPHMI_TEST_FUZZ_SEED"]) + 7)
+        nl = sc["numOfLiquidP"]
+        sc["velocity"][:nl, :3] = rng.uniform(-1.0, 1.0, size=(nl, 3)).astype(np.float32)
     if os.environ.get("SPHMI_TEST_VZ"):  # the liquid drifts along z (across the cuts): ownership must change hands during the run
         nl = sc["numOfLiquidP"]
         sc["velocity"][:nl, 2] = np.float32(os.environ["SPHMI_TEST_VZ"])
@@ -33,6 +37,11 @@ def scene():
 
 def _scene():
     # wide-mode box, long in z: 30 cell layers, lattice with a little jitter so that particles cross the cut
+    if os.environ.get("SPHMI_TEST_FUZZ_SEED"):  # tools/fuzz_slab.py: a random long box (40-100 cell layers), random fill and jitter
+        rng = np.random.default_rng(int(os.environ["SPHMI_TEST_FUZZ_SEED"]))
+        box = (float(rng.integers(6, 11)), float(rng.integers(6, 11)), float(2 * rng.integers(40, 101)))
+        lattice = tuple(int(max(2, (2.0 * b - 7.0) / 0.93 * f)) for b, f in zip(box, rng.uniform(0.6, 1.0, size=3)))
+        return scenes.liquid_box(box, lattice, mask=0xffffffff, jitter_in_r0=float(rng.uniform(0.0, 0.3)), seed=int(rng.integers(1, 1 << 30)))
     if os.environ.get("SPHMI_TEST_EIGHT_SLABS"):  # 72 layers, thin in x and y: eight slabs of nine layers
         return scenes.liquid_box((6.0, 6.0, 144.0), (8, 8, 290), mask=0xffffffff, jitter_in_r0=0.05)
     if os.environ.get("SPHMI_TEST_LONG_SCENE"):  # 42 layers: three slabs of 14, so the middle one has an interior between its two cut zones
