@@ -193,7 +193,7 @@ static bool two_hip_runtimes(char* out, size_t cap) {
 static void free_all(sph_solver* s) {
   SphDev& d = s->d;
   void* ptrs[] = {d.elasticMask, d.bndMask, d.rp, d.gatherRec, d.posOrig, d.velOrig, d.membDelta, d.sortedPos, d.sortedVel, d.predPos, d.acc, d.accP, d.keys, d.vals,
-                  d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.rho,
+                  d.keysAlt, d.valsAlt, d.backIndex, d.cellStart, d.cellStartRaw, d.nbrId, d.nbrDist, d.nbr16, d.nbrBase, d.rho,
                   d.elastic, d.membraneData, d.pml, d.muscle, d.dbg, (void*)d.binU, d.gid, d.owned, s->slabCounts,
                   s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -323,7 +323,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.rp, n); A(d.bndMask, n); A(d.gatherRec, 2 * ((n + 3) / 4 * 4));
   A(d.keys, n); A(d.vals, n); A(d.keysAlt, n); A(d.valsAlt, n); A(d.backIndex, n);
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
-  A(d.nbrId, mapN); A(d.nbrDist, mapN);
+  A(d.nbrId, mapN); A(d.nbrDist, mapN); A(d.nbr16, mapN); A(d.nbrBase, (size_t)s->capTiles * 64);
   A(d.rho, n);
   A(s->blockHist, (size_t)SPH_SORT_MAX_DIGITS * s->maxSortBlocks + SPH_SORT_MAX_DIGITS);  // block histograms + digit totals
   A(d.gid, n); A(d.owned, n); A(s->slabCounts, 12);
@@ -366,6 +366,8 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   hipMemsetAsync(d.rp, 0, sizeof(float2) * n, s->stream);
   hipMemsetAsync(d.nbrId, 0xff, sizeof(int32_t) * mapN, s->stream);
   hipMemsetAsync(d.nbrDist, 0, sizeof(float) * mapN, s->stream);
+  hipMemsetAsync(d.nbr16, 0xff, sizeof(uint16_t) * mapN, s->stream);
+  hipMemsetAsync(d.nbrBase, 0, sizeof(int32_t) * (size_t)s->capTiles * 64, s->stream);
   hipMemsetAsync(d.dbg, 0, sizeof(uint32_t) * SPH_DBG_WORDS, s->stream);
   hipMemsetAsync(d.cellStartRaw, 0, sizeof(uint32_t) * G1, s->stream);
   hipMemsetAsync(d.cellStart, 0, sizeof(uint32_t) * G1, s->stream);
@@ -721,8 +723,15 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
       const size_t mapN = (size_t)numTiles * 64 * 32;
       std::vector<int32_t> ids(mapN);
       std::vector<float> dist(mapN);
+      std::vector<uint16_t> n16(mapN);
+      std::vector<int32_t> nbase((size_t)numTiles * 64);
       rc = d2h(s, ids.data(), d.nbrId, sizeof(int32_t) * mapN);
+      if (rc == SPH_OK) rc = d2h(s, n16.data(), d.nbr16, sizeof(uint16_t) * mapN);
+      if (rc == SPH_OK) rc = d2h(s, nbase.data(), d.nbrBase, sizeof(int32_t) * nbase.size());
       if (rc == SPH_OK) rc = d2h(s, dist.data(), d.nbrDist, sizeof(float) * mapN);
+      if (rc == SPH_OK)  // the ids live in the 16-bit map (sph_common.h); the 32-bit rows only where that could not be written
+        for (size_t id = 0; id < n; id++)
+          for (int k = 0; k < 32; k++) ids[nbr_index((int)id, k)] = nbr_decode(n16.data(), nbase.data(), ids.data(), (int)id, k);
       if (rc != SPH_OK) break;
       for (size_t id = 0; id < n; id++)
         for (int k = 0; k < 32; k++) {
@@ -763,13 +772,27 @@ extern "C" int sph_read_neighbor_rows(sph_solver* s, int32_t first, int32_t coun
   std::vector<int32_t> ti;
   std::vector<float> td;
   int rc = SPH_OK;
-  if (ids) { ti.resize(words); rc = d2h(s, ti.data(), s->d.nbrId + base, sizeof(int32_t) * words); }
+  std::vector<uint16_t> t16;
+  std::vector<int32_t> tb;
+  if (ids) {
+    ti.resize(words); t16.resize(words); tb.resize((t1 - t0) * 64);
+    rc = d2h(s, ti.data(), s->d.nbrId + base, sizeof(int32_t) * words);
+    if (rc == SPH_OK) rc = d2h(s, t16.data(), s->d.nbr16 + base, sizeof(uint16_t) * words);
+    if (rc == SPH_OK) rc = d2h(s, tb.data(), s->d.nbrBase + t0 * 64, sizeof(int32_t) * tb.size());
+  }
   if (rc == SPH_OK && dist) { td.resize(words); rc = d2h(s, td.data(), s->d.nbrDist + base, sizeof(float) * words); }
   if (rc != SPH_OK) return rc;
+  const int shift = (int)(t0 * 64);  // the copies start at tile t0: decode with tile-relative particle numbers
   for (int32_t i = 0; i < count; i++)
     for (int k = 0; k < 32; k++) {
       const size_t src = nbr_index(first + i, k) - base;
-      if (ids) ids[(size_t)i * 32 + k] = ti[src];
+      if (ids) {
+        int j = nbr_decode(t16.data(), tb.data(), ti.data(), first + i - shift, k);
+        // (offsets are relative to the particle's own sorted index: undo the tile-relative numbering for the unflagged ones)
+        const uint32_t e = t16[src];
+        if (t16[nbr_index(first + i - shift, 0)] != SPH_N16_WIDE && e != SPH_N16_EMPTY && !(e & 0x8000u)) j += shift;
+        ids[(size_t)i * 32 + k] = j;
+      }
       if (dist) dist[(size_t)i * 32 + k] = td[src];
     }
   return SPH_OK;

@@ -58,6 +58,8 @@ struct SphDev {  // what the kernels see; passed by value
   uint32_t *gid, *owned;  // slab decomposition: global id and ownership flag per local particle (orig order)
   int32_t* nbrId;
   float* nbrDist;
+  uint16_t* nbr16;    // the ids again as 16-bit offsets (see nbr16_index / SPH_N16_*): what the PCISPH gather kernels stream
+  int32_t* nbrBase;   // per sorted particle: first sorted index of its z-neighbour cell, the base of the flagged offsets
   float* rho;
   float4* elastic;
   int32_t *membraneData, *pml;
@@ -125,9 +127,34 @@ __device__ __forceinline__ bool sph_range_id(const SphDev& d, int linear, int& i
 }
 #endif
 
+
 // index of (sorted particle id, slot) in the tiled neighbour map
 __host__ __device__ static inline size_t nbr_index(int id, int slot) {
   return ((((size_t)(id >> 6) * 8 + (size_t)(slot >> 2)) * 64 + (size_t)(id & 63)) << 2) + (size_t)(slot & 3);
+}
+
+// The neighbour ids a second time, 2 bytes each, in the layout of the other two maps ([tile = id/64][group = slot/4][lane = id%64]
+// [slot%4]: same element index, so findNeighbors computes one address per entry): a wave reads 4 slots of its 64 particles as
+// one contiguous 512-byte transaction and a particle's 32 ids are 64 bytes instead of 128. The three PCISPH
+// gather kernels are bound by the bytes they stream per particle, and the id rows were 40-85 % of those.
+//   entry = 0xFFFF                       empty slot
+//   entry = flag << 15 | (j - base + SPH_N16_BIAS)   with base = (flag ? nbrBase[id] : id); 0 <= low 15 bits <= SPH_N16_MAX
+//   entry 0 of a row = SPH_N16_WIDE      the row could not be encoded (an offset out of range, or the particle took the exact
+//                                        walk): readers take the 32-bit row of nbrId instead
+// Neighbours lie in the particle's own x-row of cells, the adjacent y-row (both within (cells per row + 2) x occupancy of the
+// particle itself) or the same two rows one z layer away (within that distance of the z-neighbour cell's first particle).
+#define SPH_N16_BIAS 16384
+#define SPH_N16_MAX 0x7FFD
+#define SPH_N16_EMPTY 0xFFFFu
+#define SPH_N16_WIDE 0xFFFEu
+// The sorted index in slot `slot` of particle `id` (-1: empty) from the arrays (any mix of host copies or device pointers):
+// findNeighbors writes the 32-bit row only where the 16-bit one could not be written.
+__host__ __device__ static inline int nbr_decode(const uint16_t* n16, const int32_t* nbase, const int32_t* n32, int id, int slot) {
+  const size_t row0 = nbr_index(id, 0), at = nbr_index(id, slot);
+  if (n16[row0] == SPH_N16_WIDE) return n32[at];
+  const uint32_t e = n16[at];
+  if (e == SPH_N16_EMPTY) return -1;
+  return ((e & 0x8000u) ? nbase[id] : id) + (int)(e & 0x7fffu) - SPH_N16_BIAS;
 }
 
 // ---- launchers (each enqueues on s->stream and returns SPH_OK / SPH_ERR_HIP) ----

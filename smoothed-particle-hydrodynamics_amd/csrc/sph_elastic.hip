@@ -112,7 +112,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_membranes(SphDev d, const uint32_
     float mx = 0.f, my = 0.f, mz = 0.f, dist = 0.f;
     int ijk = 0;
     if (active) {
-      const int jd = d.nbrId[nbr_index(id, lane)];
+      const int jd = nbr_decode(d.nbr16, d.nbrBase, d.nbrId, id, lane);
       const uint32_t jsrc = d.vals[jd];
       const float4 pj = d.posOrig[jsrc];
       const float vx = me.x - pj.x, vy = me.y - pj.y, vw = me.w - pj.w;  // .z zeroed, .w kept (:1436-1438)

@@ -34,17 +34,18 @@
 #include "sph_common.h"
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_clear_neighbors(int32_t* __restrict__ nbrId, float* __restrict__ nbrDist,
-                                                                size_t n4) {
+                                                                uint16_t* __restrict__ nbr16, size_t n4) {
   const size_t i = (size_t)blockIdx.x * SPH_BLOCK + threadIdx.x;
   if (i >= n4) return;
   reinterpret_cast<int4*>(nbrId)[i] = make_int4(-1, -1, -1, -1);
   reinterpret_cast<float4*>(nbrDist)[i] = make_float4(-1.f, -1.f, -1.f, -1.f);
+  if (i < n4 / 2) reinterpret_cast<int4*>(nbr16)[i] = make_int4(-1, -1, -1, -1);  // 2 bytes per slot: all SPH_N16_EMPTY
 }
 
 int sphk_clear_neighbors(sph_solver* s) {
   const size_t n4 = (size_t)((s->d.N + SPH_TILE - 1) / SPH_TILE) * 64 * 8;
   hipLaunchKernelGGL(k_clear_neighbors, dim3((unsigned)((n4 + SPH_BLOCK - 1) / SPH_BLOCK)), dim3(SPH_BLOCK), 0, s->stream,
-                     s->d.nbrId, s->d.nbrDist, n4);
+                     s->d.nbrId, s->d.nbrDist, s->d.nbr16, n4);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -60,6 +61,7 @@ struct FnArrays {  // (what the exact walk needs; built inside the kernel from i
   const uint32_t *keys, *cellStart;
   int32_t* nbrId;
   float* nbrDist;
+  uint16_t* nbr16;
 };
 
 __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFluid.cl:94-112
@@ -96,12 +98,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FN_DST_STRIDE 36           // floats per particle in the d^2 staging area (32 slots + 16 B: keeps rows 16-byte aligned)
+// rows (of 64 u16) of a wave's list area: the lists, and later per particle FN_DST_STRIDE floats of d^2 + 32 u16 of encoded ids
+#define FN_STAGE_BYTES (FN_PER_WAVE * (FN_DST_STRIDE * 4 + SPH_MAXN * 2))
+#define FN_LIST_ROWS ((FN_STAGE_BYTES + 127) / 128 > FN_LIST_CAP ? (FN_STAGE_BYTES + 127) / 128 : FN_LIST_CAP)
 
 struct FnShared {
   float x[FN_CAND_CAP + FN_CAND_PAD], y[FN_CAND_CAP + FN_CAND_PAD], z[FN_CAND_CAP + FN_CAND_PAD];  // staged candidates
   // per wave: [entry][lane] LDS slots of the filter hits, traversal order. Once a wave has expanded its lists into registers the
   // same 3 KB hold the d^2 of the accepted neighbours, [particle of the wave][slot], on their way to 16-byte map stores.
-  uint16_t list[FN_WAVES][FN_LIST_CAP][64];
+  uint16_t list[FN_WAVES][FN_LIST_ROWS][64];  // (FN_LIST_CAP rows of list; a few more so that the d^2 and id staging of the store phase fit)
   float binU[64];                                 // U[j]: d^2 < U[j]  <=>  counted in histogram bins 0..j; r_thr^2 table; filter radius (see SphDev::binU)
   int rowLo[9], rowHi[9], rowBase[9];             // staged runs: sorted-index range and first LDS slot
   int win[9][FN_WIN];                             // cellStart[] of the cells cLo-1 .. of every row (see the staging code)
@@ -110,7 +115,7 @@ struct FnShared {
   uint32_t stamps[16];                            // diagnostic build: cycles per phase, summed over the workgroup's waves
 #endif
 };
-static_assert(FN_PER_WAVE * FN_DST_STRIDE * 4 <= FN_LIST_CAP * 64 * 2, "d^2 staging must fit the wave's list area");
+static_assert(FN_LIST_ROWS >= FN_LIST_CAP, "the wave's list area holds the lists first, the staging of the store phase afterwards");
 static_assert(FN_LANES == 2 || FN_LANES == 4, "two or four lanes per particle");
 
 // DPP moves inside a quad (4 consecutive lanes = the lanes of one particle): value of lane (l ^ 1), (l ^ 2)
@@ -124,7 +129,7 @@ __device__ __forceinline__ int fn_popc(uint32_t v) { return __popc(v); }
 __device__ __forceinline__ int fn_popc(unsigned long long v) { return __popcll(v); }
 
 // d.dbg layout: [0] particles handed to the exact wave-per-particle walk because a cell was not staged, [1] because a list
-// overflowed, [3] candidate runs dropped for LDS capacity. With FN_STAMPS (diagnostic build only): [16..25] cycles / 64 per phase.
+// overflowed, [2] rows without a 16-bit copy because an offset was out of range, [3] candidate runs dropped for LDS capacity. With FN_STAMPS (diagnostic build only): [16..25] cycles / 64 per phase.
 #ifdef FN_STAMPS
 #define FN_STAMP(ph)                                                                                      \
   {                                                                                                       \
@@ -231,6 +236,7 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, const FnArrays&
     g.nbrId[idx] = -1;
     g.nbrDist[idx] = -1.f;
   }
+  if (lane == 0) g.nbr16[nbr_index(id, 0)] = (uint16_t)SPH_N16_WIDE;  // no 16-bit copy of this row: readers take the 32-bit ids
 }
 
 // Quad (4p .. 4p+3) serves particle p. Lanes 0,1 (pair A) walk the cells k = 0,5,6,7 of the reference's order and lanes 2,3
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
                                                                    const uint32_t* __restrict__ keys,
                                                                    const uint32_t* __restrict__ cellStart,
                                                                    const float* __restrict__ binU, int32_t* __restrict__ nbrId,
-                                                                   float* __restrict__ nbrDist, uint32_t* __restrict__ dbg,
+                                                                   float* __restrict__ nbrDist, uint16_t* __restrict__ nbr16,
+                                                                   int32_t* __restrict__ nbrBase, uint32_t* __restrict__ dbg,
                                                                    uint32_t* __restrict__ trace) {  // trace: FN_STAMPS builds only
   extern __shared__ __align__(16) unsigned char fn_smem[];
   FnShared& sh = *reinterpret_cast<FnShared*>(fn_smem);
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   const int id = p0 + p;
   const bool alive = id < rangeEnd;
   FnArrays g;
-  g.sortedPos = sortedPos; g.keys = keys; g.cellStart = cellStart; g.nbrId = nbrId; g.nbrDist = nbrDist;
+  g.sortedPos = sortedPos; g.keys = keys; g.cellStart = cellStart; g.nbrId = nbrId; g.nbrDist = nbrDist; g.nbr16 = nbr16;
 #ifdef FN_STAMPS
   const unsigned long long wgStart_ = __builtin_amdgcn_s_memrealtime();  // 100 MHz
   if (tid < 16) sh.stamps[tid] = 0u;
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   asm volatile("" : "+v"(me.x), "+v"(me.y), "+v"(me.z), "+v"(myCellNow), "+v"(idNow));
   int pLo[4], pHi[4], absDelta[4];  // this lane's four pieces as LDS slot ranges; sorted index = LDS slot + absDelta
   int selfSlot = -1;
+  int zLoMine = 0;  // pair B: first sorted index of cell 3, the z neighbour (base of the flagged 16-bit offsets)
   {  // the lane's four cells (sphFluid.cl:253-308) with the cell table read from the LDS window where possible
     const float px = me.x - d.xmin, py = me.y - d.ymin, pz = me.z - d.zmin;
     const float cfx = (float)(int)(me.x * d.cellSizeInv) * d.cellSize;
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
       pLo[i] = sub ? mid : base;
       pHi[i] = sub ? base + n : mid;
       absDelta[i] = lo - base;
+      if (i == 2) zLoMine = lo;
       if (i == 0 && pairB == 0) selfSlot = base + (idNow - lo);  // the particle itself sits in its own cell
     }
   }
@@ -607,6 +616,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   const int partner = grp_other_half(packed);   // the other half of the same four cells (none with two lanes per particle)
   const int cellTot = packed + partner;         // whole-cell counts of this pair (bytes <= 48: no carry)
   const int otherTot = grp_other_pair(cellTot); // whole-cell counts of the other pair
+  const int zLoOther = grp_other_pair(zLoMine);  // (a DPP move: executed by all lanes of the particle)
   // (the wave's list area is free from here on: every lane has its slots in slotPk, and LDS operations of a wave retire in order)
   if (!slow) {
     const int c0b = cellTot & 255, c1b = (cellTot >> 8) & 255, c2b = (cellTot >> 16) & 255, c3b = (cellTot >> 24) & 255;
@@ -624,9 +634,33 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
     // Ids go straight to the tiled map (4-byte stores); the d^2 of the accepted neighbours go to the wave's staging area
     // [particle][slot], from which every lane of the quad then takes 8 consecutive slots: 8 square roots per lane instead of
     // one per list entry, and the distances leave as two 16-byte stores per lane (which also write the -1 of the unused slots).
+    // The 16-bit copy of the row (sph_common.h, SPH_N16_*): offsets from the particle itself, or — cells one z layer away: pair A's
+    // 5 6 7, pair B's 3 — from the first particle of the z-neighbour cell. A piece's entries are its LDS slots + one constant, so
+    // the range check is two comparisons per piece, not one per entry.
+    const int zBase = pairB ? zLoMine : zLoOther;
+    int rel16[4];
+    int wide = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool zf = pairB ? (i == 2) : (i != 0);
+      rel16[i] = absDelta[i] - (zf ? zBase : idNow) + SPH_N16_BIAS;
+      if (pHi[i] > pLo[i] && (pLo[i] + rel16[i] < 0 || pHi[i] - 1 + rel16[i] > SPH_N16_MAX)) wide = 1;
+    }
+    // (per entry below: the offset from the particle itself if that fits, else the flagged one — which fits where the checks above
+    // passed; the reader only follows the flag, so no per-piece bookkeeping is needed)
+    int own16 = SPH_N16_BIAS - idNow, far16 = SPH_N16_BIAS + 0x8000 - zBase;
+    asm volatile("" : "+v"(own16), "+v"(far16));  // (kept in registers: rematerialised per entry they cost two more instructions each)
+    wide |= grp_other_half(wide);  // (both lanes are in this branch: `slow` is agreed inside the particle)
+    wide |= grp_other_pair(wide);
     int tidNow = tid;  // (opaque: keeps the address below from being hoisted to the kernel's prologue and spilled)
     asm volatile("" : "+v"(tidNow));
-    float* const dstRow = reinterpret_cast<float*>(&sh.list[0][0][0]) + (tidNow >> 6) * (FN_LIST_CAP * 64 / 2) + ((tidNow & 63) >> FN_LOG_LANES) * FN_DST_STRIDE;
+    float* const waveArea = reinterpret_cast<float*>(&sh.list[0][0][0]) + (tidNow >> 6) * (FN_LIST_ROWS * 64 / 2);
+    float* const dstRow = waveArea + ((tidNow & 63) >> FN_LOG_LANES) * FN_DST_STRIDE;
+    // the row's 16-bit entries, [particle of the wave][slot], behind the d^2 area; pre-filled with "empty" by the lane that will store them
+    uint16_t* const idRow = reinterpret_cast<uint16_t*>(waveArea + FN_PER_WAVE * FN_DST_STRIDE) + ((tidNow & 63) >> FN_LOG_LANES) * SPH_MAXN;
+#pragma unroll
+    for (int v = 0; v < FN_SLOTS_PER_LANE / 8; v++)
+      *reinterpret_cast<uint4*>(idRow + FN_SLOTS_PER_LANE * quadLane + 8 * v) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     const uint32_t mapBase = ((uint32_t)(idNow >> 6) * (8u * 64u) + (uint32_t)(idNow & 63)) << 2;  // element index of slot 0 (< 2^32: N <= 2^27)
     // walk the entries in list order with a running (piece start, index delta, rank inside the piece)
     int curStart = start[0], curDelta = absDelta[0], rank = 0;
@@ -643,14 +677,53 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
           const int pos = curStart + rank;
           rank++;
           if (pos < SPH_MAXN) {
-            nbrId[mapBase + (uint32_t)(((pos >> 2) << 8) + (pos & 3))] = (int)((slotPk[e >> 1] >> ((e & 1) * 16)) & 0xffffu) + curDelta;  // tiled map: group stride 64 lanes * 4 slots
+            const int jn = (int)((slotPk[e >> 1] >> ((e & 1) * 16)) & 0xffffu) + curDelta;
+            const int o16 = jn + own16;
+            idRow[pos] = (uint16_t)((uint32_t)o16 <= (uint32_t)SPH_N16_MAX ? o16 : jn + far16);
             dstRow[pos] = d2v[e];
           }
         }
       }
     }
-    for (int k = run + quadLane; k < SPH_MAXN; k += FN_LANES) nbrId[mapBase + (uint32_t)(((k >> 2) << 8) + (k & 3))] = -1;  // K1 folded in: unused id slots
+    if (__any(wide != 0)) {
+    // (rare) rows without a 16-bit copy: the same walk once more, for the 32-bit ids
+    int curStart = start[0], curDelta = absDelta[0], rank = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < FN_LIST_CAP; c0 += FN_CHUNK) {
+      if (!__any(c0 < total)) continue;  // wave-uniform skip of empty chunks
+#pragma unroll
+      for (int u = 0; u < FN_CHUNK; u++) {
+        const int e = c0 + u;
+        if (e == segEnd[0]) { curStart = start[1]; curDelta = absDelta[1]; rank = 0; }  // (empty pieces cascade in order)
+        if (e == segEnd[1]) { curStart = start[2]; curDelta = absDelta[2]; rank = 0; }
+        if (e == segEnd[2]) { curStart = start[3]; curDelta = absDelta[3]; rank = 0; }
+        if ((acc >> e) & 1) {
+          const int pos = curStart + rank;
+          rank++;
+          if (pos < SPH_MAXN) {
+            const int jn = (int)((slotPk[e >> 1] >> ((e & 1) * 16)) & 0xffffu) + curDelta;
+            if (wide) nbrId[mapBase + (uint32_t)(((pos >> 2) << 8) + (pos & 3))] = jn;  // tiled map: group stride 64 lanes * 4 slots
+          }
+        }
+      }
+    }
+    }
+    if (wide) {  // K1 folded in: unused slots of the 32-bit row (the 16-bit ones are pre-filled)
+      for (int k = run + quadLane; k < SPH_MAXN; k += FN_LANES) nbrId[mapBase + (uint32_t)(((k >> 2) << 8) + (k & 3))] = -1;
+    }
+    if (quadLane == 0) nbrBase[idNow] = zBase;
     const uint32_t mapMine = mapBase + (uint32_t)((FN_SLOTS_PER_LANE / 4) * quadLane) * 256u;  // this lane's first group of 4 slots
+    // the 16-bit ids: every lane takes FN_SLOTS_PER_LANE consecutive slots of the particle from the staging area, 8 bytes per group of 4
+#pragma unroll
+    for (int v = 0; v < FN_SLOTS_PER_LANE / 8; v++) {
+      const uint4 q = *reinterpret_cast<const uint4*>(idRow + FN_SLOTS_PER_LANE * quadLane + 8 * v);
+      *reinterpret_cast<uint2*>(nbr16 + (size_t)(mapMine + (uint32_t)(2 * v) * 256u)) = make_uint2(q.x, q.y);
+      *reinterpret_cast<uint2*>(nbr16 + (size_t)(mapMine + (uint32_t)(2 * v + 1) * 256u)) = make_uint2(q.z, q.w);
+    }
+    if (wide && quadLane == 0) {  // (after the entries: stores of one wave to one address keep their order)
+      nbr16[mapBase] = (uint16_t)SPH_N16_WIDE;
+      atomicAdd(&dbg[2], 1u);
+    }
 #pragma unroll
     for (int gq = 0; gq < FN_SLOTS_PER_LANE / 4; gq++) {
       const f32x4 dq = *reinterpret_cast<const f32x4*>(dstRow + FN_SLOTS_PER_LANE * quadLane + 4 * gq);
@@ -706,7 +779,8 @@ int sphk_find_neighbors(sph_solver* s, int ghostDepth) {
   a.h = r.h; a.cellSize = r.cellSize; a.cellSizeInv = r.cellSizeInv; a.simScale = r.simScale;
   a.xmin = r.xmin; a.ymin = r.ymin; a.zmin = r.zmin;
   hipLaunchKernelGGL(k_find_neighbors, dim3(sph_blocks(s->d.N, FN_PART)), dim3(FN_THREADS), sizeof(FnShared), s->stream, a,
-                     (const float4*)r.sortedPos, (const uint32_t*)r.keys, (const uint32_t*)r.cellStart, r.binU, r.nbrId, r.nbrDist, r.dbg,
+                     (const float4*)r.sortedPos, (const uint32_t*)r.keys, (const uint32_t*)r.cellStart, r.binU, r.nbrId, r.nbrDist, r.nbr16,
+                     r.nbrBase, r.dbg,
                      r.valsAlt /* idle between the sort and the next step's sort */);
   SPH_HIP(hipGetLastError());
   return SPH_OK;

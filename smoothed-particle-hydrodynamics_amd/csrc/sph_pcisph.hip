@@ -33,17 +33,35 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 // index into SphDev::gatherRec: groups of four particles, [4 x part 0][4 x part 1] (one 128-byte line; see k_pack_gather_records)
 __device__ __forceinline__ size_t rec_index(int j, int part) { return ((size_t)(j >> 2) << 3) + (size_t)(part << 2) + (size_t)(j & 3); }
 
-// the 8 x (int4 ids, float4 dists) of particle `id`
+// the 8 x (int4 ids, float4 dists) of particle `id`, and its ids again as 8 x (4 x 16-bit offsets) (sph_common.h, SPH_N16_*)
 struct NbrTile {
   const int4* ids;
   const float4* dist;
+  const uint2* v16;
+  int self, zOff;  // the particle and (base of its flagged offsets) - (the particle)
   __device__ __forceinline__ NbrTile(const SphDev& d, int id) {
     const size_t base = ((size_t)(id >> 6) * 8) * 64 + (size_t)(id & 63);
     ids = reinterpret_cast<const int4*>(d.nbrId) + base;
     dist = reinterpret_cast<const float4*>(d.nbrDist) + base;
+    v16 = reinterpret_cast<const uint2*>(d.nbr16) + base;
+    self = id;
+    zOff = d.nbrBase[id] - id;
   }
   __device__ __forceinline__ int4 id4(int g) const { return ids[(size_t)g * 64]; }
   __device__ __forceinline__ float4 dist4(int g) const { return dist[(size_t)g * 64]; }
+  __device__ __forceinline__ uint2 vec16(int g) const { return v16[(size_t)g * 64]; }  // slots 4g .. 4g+3
+  // the row has no 16-bit copy (an offset did not fit, or findNeighbors served the particle by its exact walk): use id_wide()
+  __device__ __forceinline__ static bool wide(const uint2& group0) { return (group0.x & 0xffffu) == SPH_N16_WIDE; }
+  __device__ __forceinline__ int id_wide(int slot) const {
+    return reinterpret_cast<const int32_t*>(ids)[((size_t)(slot >> 2) * 64) * 4 + (size_t)(slot & 3)];
+  }
+  // entry k (0..3) of a group -> sorted index of the neighbour, -1 for an empty slot
+  __device__ __forceinline__ int decode(const uint2& v, int k) const {
+    const uint32_t w = (k >> 1) == 0 ? v.x : v.y;
+    const uint32_t e = (k & 1) ? (w >> 16) : (w & 0xffffu);
+    const int j = self - SPH_N16_BIAS + (int)(e & 0x7fffu) + ((e & 0x8000u) ? zOff : 0);
+    return e == SPH_N16_EMPTY ? -1 : j;
+  }
 };
 
 // XCD-aware block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs; remap so that each
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
   float sx = 0.f, sy = 0.f, sz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
   uint32_t bnd = 0u, ela = 0u;  // which neighbour slots hold boundary / elastic particles: saves integrate and the
                                 // membrane kernel 32 type gathers per particle
+  bool wideRow = false;
   // Branch-free (see k_predict_density): per batch of FC_BATCH neighbours the map loads, then all gathers in flight together.
   // The map is read batch by batch (not all 32 entries up front) and the velocity gather takes 12 bytes: at 193 VGPRs the
   // kernel ran two waves per SIMD, too few to cover its gathers.
@@ -188,10 +207,19 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
     float rr[FC_BATCH];
 #pragma unroll
     for (int q = 0; q < FC_BATCH / 4; q++) {
-      const int4 jq = t.id4(b * (FC_BATCH / 4) + q);
       const float4 rq = t.dist4(b * (FC_BATCH / 4) + q);
-      jj[4 * q] = jq.x; jj[4 * q + 1] = jq.y; jj[4 * q + 2] = jq.z; jj[4 * q + 3] = jq.w;
       rr[4 * q] = rq.x; rr[4 * q + 1] = rq.y; rr[4 * q + 2] = rq.z; rr[4 * q + 3] = rq.w;
+    }
+#pragma unroll
+    for (int q = 0; q < FC_BATCH / 4; q++) {
+      const uint2 v = t.vec16(b * (FC_BATCH / 4) + q);
+      if (b == 0 && q == 0) wideRow = NbrTile::wide(v);
+#pragma unroll
+      for (int k = 0; k < 4; k++) jj[4 * q + k] = t.decode(v, k);
+    }
+    if (wideRow) {  // rare
+#pragma unroll
+      for (int k = 0; k < FC_BATCH; k++) jj[k] = t.id_wide(b * FC_BATCH + k);
     }
     float4 xj[FC_BATCH], vr[FC_BATCH];
 #pragma unroll
@@ -289,9 +317,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
   const NbrTile t(d, id);
   // Branch-free: all 8 id loads first, then the gathers in batches of 8 with an always-valid index (empty slots read
   // record 0 and are masked out of the sum), so a wave keeps 8 gathers in flight instead of one per `if`.
-  int4 j4[8];
+  uint2 v16[8];  // the ids as 16-bit offsets: 64 bytes per particle instead of 128 (this kernel streams little else)
 #pragma unroll
-  for (int g = 0; g < 8; g++) j4[g] = t.id4(g);
+  for (int g = 0; g < 8; g++) v16[g] = t.vec16(g);
+  const bool wideRow = NbrTile::wide(v16[0]);
   double density = 0.0;
 #pragma unroll
   for (int b = 0; b < 32 / PD_BATCH; b++) {
@@ -299,8 +328,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_predict_density(SphDev d, int nbl
 #pragma unroll
     for (int k = 0; k < PD_BATCH; k++) {
       const int slot = b * PD_BATCH + k;
-      const int4 jq = j4[slot >> 2];
-      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
+      jj[k] = t.decode(v16[slot >> 2], slot & 3);
+    }
+    if (wideRow) {  // rare
+#pragma unroll
+      for (int k = 0; k < PD_BATCH; k++) jj[k] = t.id_wide(b * PD_BATCH + k);
     }
     float4 xj[PD_BATCH];
 #pragma unroll
@@ -370,14 +402,14 @@ __device__ __forceinline__ void integrate_particle(const SphDev& d, int id, cons
   float ncx = 0.f, ncy = 0.f, ncz = 0.f, ncw = 0.f, wsum = 0.f, wsum2 = 0.f;
   const uint32_t bnd = d.bndMask[id];  // boundary neighbours, found by the forces kernel of this step
   if (__any(bnd != 0u)) {              // waves in the bulk of the liquid skip the loop (and its 32 id loads) entirely
+    const bool wideRow = NbrTile::wide(t.vec16(0));
 #pragma unroll 2
     for (int g = 0; g < 8; g++) {
-      const int4 j4 = t.id4(g);
-      const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+      const uint2 v = t.vec16(g);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (!((bnd >> (g * 4 + k)) & 1u)) continue;
-        const int jb = jj[k];
+        const int jb = wideRow ? t.id_wide(g * 4 + k) : t.decode(v, k);
         const float4 pb = d.sortedPos[jb];
         float dist = (nx - pb.x) * (nx - pb.x);
         dist += (ny - pb.y) * (ny - pb.y);
@@ -448,10 +480,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   const float hq = d.hs * 0.25f;
   // Branch-free, like k_predict_density: map loads first, gathers in batches of PF_BATCH with an always-valid index,
   // masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`).
-  int4 j4[8];
+  uint2 v16[8];
   float4 r4[8];
 #pragma unroll
-  for (int g = 0; g < 8; g++) { j4[g] = t.id4(g); r4[g] = t.dist4(g); }
+  for (int g = 0; g < 8; g++) { v16[g] = t.vec16(g); r4[g] = t.dist4(g); }
+  const bool wideRow = NbrTile::wide(v16[0]);
 #pragma unroll
   for (int b = 0; b < 32 / PF_BATCH; b++) {
     int jj[PF_BATCH];
@@ -459,10 +492,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const int slot = b * PF_BATCH + k;
-      const int4 jq = j4[slot >> 2];
       const float4 rq = r4[slot >> 2];
-      jj[k] = (slot & 3) == 0 ? jq.x : (slot & 3) == 1 ? jq.y : (slot & 3) == 2 ? jq.z : jq.w;
+      jj[k] = t.decode(v16[slot >> 2], slot & 3);
       rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
+    }
+    if (wideRow) {  // rare
+#pragma unroll
+      for (int k = 0; k < PF_BATCH; k++) jj[k] = t.id_wide(b * PF_BATCH + k);
     }
     float4 xj[PF_BATCH];
     float2 rpj[PF_BATCH];
