@@ -43,13 +43,15 @@ WORKLOADS = {
 
 DEFAULT_WORKLOAD = "config4_16M_box"
 
-# SURVEY App. D, lean SoA layout: algorithmic bytes per particle of every launch of a stage in one step (pure liquid,
-# 3 predict-correct iterations). sort = 3 radix passes of wide ids x (8 R hist + 8 R + 8 W scatter); find_neighbors 268;
-# density 132; forces ~300 (+32 for the (v, rho) pack); predict_density 3 x 152 (correctPressure fused);
-# pressure_force 2 x (288 + 48 predictPositions) + (288 + 200 integrate).
+# Algorithmic bytes per particle of every launch of a stage in one step (pure liquid, 3 predict-correct iterations), for the
+# layout the kernels actually use: neighbour ids as 16-bit offsets (64 B per row + a 4-byte base), distances 128 B per row.
+# sort = radix passes x (4 R hist + 8 R + 8 W scatter + 4); find_neighbors 16 + 4 in, 64 + 128 + 4 out; density 132; forces
+# 64 + 4 + 128 in + own records and outputs 44, + 32 for the (v, rho) pack; predict_density 3 x (64 + 4 + 16 + 8); pressure_force
+# (distances recomputed from the gathered positions: none read) 2 x (68 + 24 + 48 predictPositions + 16) + (68 + 24 + 200 integrate).
+# SURVEY App. D's lean layout with 4-byte ids is 2.6 KB per particle and step: `whole_step_2600B` keeps that yardstick.
 STAGE_ALGO_BYTES = {"hash": 20, "sort": 72,  # (sort: 24 B per radix pass, set from the solver's pass count below)
-                    "sort_post": 69, "find_neighbors": 268, "density": 132, "forces": 332,
-                    "predict_density": 456, "pressure_force": 1160}
+                    "sort_post": 69, "find_neighbors": 216, "density": 132, "forces": 272,
+                    "predict_density": 276, "pressure_force": 604}
 
 
 def weak_workload(world):
@@ -218,6 +220,9 @@ def main():
         step_ms = sum(stages_ms.values())
         if step_ms > 0:
             stages_frac["whole_step_2600B"] = round(n_local * 2600.0 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            moved = sum(algo[k] for k in stages_ms if k in algo)
+            stages_frac["whole_step_bytes_moved"] = moved
+            stages_frac["whole_step_moved"] = round(n_local * moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     # Multi-GPU sanity after the timed region (outside `value`): the ranks' owned sets must still partition the particles and
     # every owned particle must be finite — a silent halo failure would show here.

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_forces(SphDev d, int nblocks) 
     int jj[FC_BATCH];
     float rr[FC_BATCH];
 #pragma unroll
-    for (int q = 0; q < FC_BATCH / 4; q++) {
+    for (int q = 0; q < FC_BATCH / 4; q++) {  // (recomputing r from the gathered positions, as K12 does, is not faster here: 1.505 vs 1.521 ms)
       const float4 rq = t.dist4(b * (FC_BATCH / 4) + q);
       rr[4 * q] = rq.x; rr[4 * q + 1] = rq.y; rr[4 * q + 2] = rq.z; rr[4 * q + 3] = rq.w;
     }
@@ -480,21 +480,20 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   const float hq = d.hs * 0.25f;
   // Branch-free, like k_predict_density: map loads first, gathers in batches of PF_BATCH with an always-valid index,
   // masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`).
+  // The distances are NOT read: r_ij is recomputed from the two position records this kernel has anyway, with the expression
+  // findNeighbors stored it with (sphFluid.cl:131-136,172; IEEE sqrt) — bit-identical, and 128 of the 272 bytes the kernel
+  // streamed per particle are gone (1.24 -> 1.17 ms per launch at 16.5 M particles).
   uint2 v16[8];
-  float4 r4[8];
 #pragma unroll
-  for (int g = 0; g < 8; g++) { v16[g] = t.vec16(g); r4[g] = t.dist4(g); }
+  for (int g = 0; g < 8; g++) v16[g] = t.vec16(g);
   const bool wideRow = NbrTile::wide(v16[0]);
 #pragma unroll
   for (int b = 0; b < 32 / PF_BATCH; b++) {
     int jj[PF_BATCH];
-    float rr[PF_BATCH];
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
       const int slot = b * PF_BATCH + k;
-      const float4 rq = r4[slot >> 2];
       jj[k] = t.decode(v16[slot >> 2], slot & 3);
-      rr[k] = (slot & 3) == 0 ? rq.x : (slot & 3) == 1 ? rq.y : (slot & 3) == 2 ? rq.z : rq.w;
     }
     if (wideRow) {  // rare
 #pragma unroll
@@ -510,7 +509,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
     }
 #pragma unroll
     for (int k = 0; k < PF_BATCH; k++) {
-      const float r = rr[k];
+      const float ex_ = xi.x - xj[k].x, ey_ = xi.y - xj[k].y, ez_ = xi.z - xj[k].z;
+      const float r = sqrtf(ex_ * ex_ + ey_ * ey_ + ez_ * ez_) * d.simScale;  // == the stored neighborMap distance
       // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
       // the numerator is selected first, so only one IEEE division is spent
       const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
