@@ -4,8 +4,9 @@
 //   sorted order (per step)     sortedPos float4[N] (x,y,z,type)       sortedVel float4[N]     predPos float4[N]
 //                               keys u32[N] (cell)  vals u32[N] (orig id)  backIndex u32[N] (orig -> sorted)
 //                               rho f32[N]   rp float2[N] (rhoPred, pressure)   acc / accP float4[N]
-//   neighbour map, tiled        nbrId i32, nbrDist f32: [tile = id/64][group = slot/4][lane = id%64][slot%4]
-//                               -> one wave reads 4 slots of its 64 particles as ONE contiguous 1-KiB transaction
+//   neighbour map, tiled        nbr16 u16 (ids as offsets), nbrDist f32, nbrId i32 (rows nbr16 cannot hold):
+//                               [tile = id/64][group = slot/4][lane = id%64][slot%4]
+//                               -> one wave reads 4 slots of its 64 particles as ONE contiguous 512-B / 1-KiB transaction
 //   grid                        cellStart u32[G+1]  (== gridCellIndexFixedUp: #particles with cell < c)
 //
 // float4 is kept for everything that other particles gather (one 16-B transaction per neighbour instead of

@@ -7,20 +7,18 @@
 //
 // MI355X design. The reference walks ~640 candidates twice per particle and does the expensive part
 // (sqrt, IEEE divide, histogram / store) under a branch that ~7 % of the lanes take but ~99 % of the waves execute.
-// Here a 512-thread workgroup owns 128 consecutive sorted particles, FOUR lanes per particle (a DPP quad), stages the <= 9
-// contiguous runs of sorted particles that can contain their candidates (cells are contiguous along x in the sorted
-// order) into LDS once as SoA x/y/z, and each lane
-//   1. walks one HALF of four of the particle's 8 cells ONCE (~160 candidates), four candidates per trip (16-byte aligned
-//      LDS reads, packed-f32 math, next quad prefetched), with the cheap filter d^2 <= max(h, 31h/30)^2 — a superset of both
-//      reference passes — and appends the LDS slot of every hit to a private u16 list in LDS (~12 of ~160 survive),
-//   2. replays pass 0 / threshold / pass 1 of the reference over that short list in registers (24 entries), in traversal
+// Here a 256-thread workgroup owns 128 consecutive sorted particles, TWO lanes per particle (FN_LANES; four were measured:
+// slower), stages the <= 9 contiguous runs of sorted particles that can contain their candidates (cells are contiguous along x
+// in the sorted order) into LDS once as SoA x/y/z, and each lane
+//   1. walks four of the particle's 8 cells ONCE (~280 candidates), four candidates per trip (16-byte aligned LDS reads,
+//      packed-f32 math, next quad prefetched), with the cheap filter d^2 <= max(h, 31h/30)^2 — a superset of both reference
+//      passes — and appends the LDS slot of every hit to a private u16 list in LDS (~20 of ~280 survive),
+//   2. replays pass 0 / threshold / pass 1 of the reference over that short list in registers (48 entries), in traversal
 //      order, with exactly the reference's float expressions, so r_thr, slot order and distances are bit-identical. Pass 0
 //      does not build the histogram: the cumulative counts it needs are "d^2 < U[j]" tests against 30 thresholds computed
-//      exactly on the host (binU), searched by bisection; counts are combined inside the quad with DPP adds.
-// Why quads: the round-1 kernel (two lanes per particle, 48-entry register arrays) needed 247 VGPRs and 74 KB of LDS per
-// 4 waves — 2 waves per SIMD — and its waves spent 44 % of their cycles waiting with nobody to cover for them (rocprofv3 SQ
-// counters, profiles/r02). Four lanes per particle halve both the list length and the per-wave LDS: <= 128 VGPRs and
-// 75 KB per 8 waves, i.e. 4 waves per SIMD.
+//      exactly on the host (binU), searched by bisection; counts are combined inside the particle's lanes with DPP adds,
+//   3. stores the row: ids as 16-bit offsets (sph_common.h, SPH_N16_*) and d^2, staged per wave in LDS as [particle][slot],
+//      leave as 8- and 16-byte vectors per lane (square roots taken on the way out).
 // Particles whose list overflows or whose cells are not fully staged (wrapped / aliased cells, LDS capacity) are served at
 // the end of the batch by the literal two-pass walk, one WAVE per particle, reading the staged candidates from LDS where
 // they are staged and from global memory otherwise — so the result is exact for any input and no second kernel or queue

@@ -1,8 +1,9 @@
 // PCISPH kernels K6, K7, K9-K13 (sphFluid.cl:472-708, 824-1212, 1684-1808) for gfx950.
 //
 // One lane per sorted particle (the reference's `id = particleIndexBack[get_global_id]` is a pure thread permutation and
-// is dropped — SURVEY App. B #11). Every kernel streams its own 32 neighbour slots as eight coalesced 16-byte loads
-// per lane from the tiled map (1 KiB per wave-instruction) and gathers neighbour state as single float4 transactions.
+// is dropped — SURVEY App. B #11). Every kernel streams its own 32 neighbour slots from the tiled maps — the ids as 16-bit
+// offsets, eight coalesced 8-byte loads per lane (NbrTile; sph_common.h, SPH_N16_*), the distances where it needs them as eight
+// 16-byte loads — and gathers neighbour state as single 12/16-byte transactions.
 // Arithmetic keeps the reference's operand types and evaluation order: no FMA contraction, IEEE division/sqrt,
 // f32 denormals kept, f64 where sphFluid.cl uses double.
 #include "sph_common.h"
