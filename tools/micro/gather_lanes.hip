@@ -3,6 +3,7 @@
 //   mode 1: raw buffer load, a fraction of the lanes out of range (dropped by the address unit)
 //   mode 2: global load under an exec mask (if), same fraction of lanes switched off
 //   mode 3: global load, the same fraction of lanes redirected to their own (coalesced) record
+//   mode 4: all lanes, records packed at a 12-byte stride
 // Build: hipcc --offload-arch=gfx950 -O3 -o gather_lanes gather_lanes.hip ; run: ./gather_lanes
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,6 +35,10 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ rec, const i
       }
       if (MODE == 2) { x[k2] = y[k2] = z[k2] = 0.f; if (keep) { const float4 v = rec[jj]; x[k2] = v.x; y[k2] = v.y; z[k2] = v.z; } }
       if (MODE == 3) { const float4 v = rec[keep ? jj : id]; x[k2] = v.x; y[k2] = v.y; z[k2] = v.z; }
+      if (MODE == 4) {  // records packed at a 12-byte stride (10.7 per 128-byte line instead of 8)
+        const float* p3 = reinterpret_cast<const float*>(rec) + (size_t)jj * 3;
+        x[k2] = p3[0]; y[k2] = p3[1]; z[k2] = p3[2];
+      }
     }
 #pragma unroll
     for (int k2 = 0; k2 < 8; k2++) s += x[k2] * y[k2] + z[k2];
@@ -59,9 +64,9 @@ int main() {
   CHECK(hipMemcpy(dNbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const int keeps[5] = {1024, 768, 512, 340, 0};
-  for (int mode = 0; mode < 4; mode++)
+  for (int mode = 0; mode < 5; mode++)
     for (int ki = 0; ki < 5; ki++) {
-      if (mode == 0 && ki) continue;
+      if ((mode == 0 || mode == 4) && ki) continue;
       const int keep = keeps[ki];
       for (int rep = 0; rep < 23; rep++) {
         if (rep == 3) CHECK(hipEventRecord(e0));
@@ -69,6 +74,7 @@ int main() {
         if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(n / 256), dim3(256), 0, 0, dRec, dNbr, dOut, n, keep);
         if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(n / 256), dim3(256), 0, 0, dRec, dNbr, dOut, n, keep);
         if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(n / 256), dim3(256), 0, 0, dRec, dNbr, dOut, n, keep);
+        if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(n / 256), dim3(256), 0, 0, dRec, dNbr, dOut, n, keep);
       }
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
