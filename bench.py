@@ -46,12 +46,12 @@ DEFAULT_WORKLOAD = "config4_16M_box"
 # Algorithmic bytes per particle of every launch of a stage in one step (pure liquid, 3 predict-correct iterations), for the
 # layout the kernels actually use: neighbour ids as 16-bit offsets (64 B per row + a 4-byte base), distances 128 B per row.
 # sort = radix passes x (4 R hist + 8 R + 8 W scatter + 4); find_neighbors 16 + 4 in, 64 + 128 + 4 out; density 132; forces
-# 64 + 4 + 128 in + own records and outputs 44, + 32 for the (v, rho) pack; predict_density 3 x (64 + 4 + 16 + 8); pressure_force
+# 64 + 4 + 128 in + own records and outputs 44, + 32 for the (v, rho) pack; predict_density 3 x (64 + 4 + 12 + 8; predicted positions are packed x, y, z); pressure_force
 # (distances recomputed from the gathered positions: none read) 2 x (68 + 24 + 48 predictPositions + 16) + (68 + 24 + 200 integrate).
 # SURVEY App. D's lean layout with 4-byte ids is 2.6 KB per particle and step: `whole_step_2600B` keeps that yardstick.
 STAGE_ALGO_BYTES = {"hash": 20, "sort": 72,  # (sort: 24 B per radix pass, set from the solver's pass count below)
-                    "sort_post": 69, "find_neighbors": 216, "density": 132, "forces": 272,
-                    "predict_density": 276, "pressure_force": 604}
+                    "sort_post": 69, "find_neighbors": 216, "density": 132, "forces": 268,
+                    "predict_density": 264, "pressure_force": 596}
 
 
 def weak_workload(world):

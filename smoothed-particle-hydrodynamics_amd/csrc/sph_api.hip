@@ -320,7 +320,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   int rc = SPH_OK;
   const size_t n = (size_t)cap, nUp = (size_t)N, G1 = (size_t)d.G + 1, mapN = (size_t)s->capTiles * 64 * 32;
 #define A(ptr, count) if (rc == SPH_OK) rc = dev_alloc(&(ptr), (count))
-  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, n); A(d.acc, n); A(d.accP, n); A(d.rp, n); A(d.bndMask, n); A(d.gatherRec, 2 * ((n + 3) / 4 * 4));
+  A(d.posOrig, n); A(d.velOrig, n); A(d.sortedPos, n); A(d.sortedVel, n); A(d.predPos, 3 * n); A(d.acc, n); A(d.accP, n); A(d.rp, n); A(d.bndMask, n); A(d.gatherRec, 2 * ((n + 3) / 4 * 4));
   A(d.keys, n); A(d.vals, n); A(d.keysAlt, n); A(d.valsAlt, n); A(d.backIndex, n);
   A(d.cellStart, G1); A(d.cellStartRaw, G1);
   A(d.nbrId, mapN); A(d.nbrDist, mapN); A(d.nbr16, mapN); A(d.nbrBase, (size_t)s->capTiles * 64);
@@ -359,7 +359,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   }
 #undef UP
   // buffers the reference leaves uninitialised but that an export may read before they are written
-  hipMemsetAsync(d.predPos, 0, sizeof(float4) * n, s->stream);
+  hipMemsetAsync(d.predPos, 0, sizeof(float) * 3 * n, s->stream);
   hipMemsetAsync(d.acc, 0, sizeof(float4) * n, s->stream);
   hipMemsetAsync(d.accP, 0, sizeof(float4) * n, s->stream);
   hipMemsetAsync(d.rho, 0, sizeof(float) * n, s->stream);
@@ -699,7 +699,12 @@ extern "C" int sph_read_buffer(sph_solver* s, const char* name, void* out, size_
       std::vector<uint32_t> k(n);
       std::vector<float4> sv(n);
       rc = d2h(s, o, d.sortedPos, sizeof(float4) * n);
-      if (rc == SPH_OK) rc = d2h(s, o + sizeof(float4) * n, d.predPos, sizeof(float4) * n);
+      if (rc == SPH_OK) {  // the predicted half: packed (x, y, z) on the device; .w is dead data in the reference
+        std::vector<float> p3(3 * n);
+        rc = d2h(s, p3.data(), d.predPos, sizeof(float) * 3 * n);
+        float4* half = (float4*)(o + sizeof(float4) * n);
+        if (rc == SPH_OK) for (size_t i = 0; i < n; i++) half[i] = make_float4(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2], 0.f);
+      }
       if (rc == SPH_OK) rc = d2h(s, k.data(), d.keys, sizeof(uint32_t) * n);
       if (rc == SPH_OK) rc = d2h(s, sv.data(), d.sortedVel, sizeof(float4) * n);
       if (rc != SPH_OK) break;

@@ -1,7 +1,7 @@
 // Internal declarations of libsphmi.so (gfx950 only). Data layout in HBM — see DESIGN.md §3.
 //
 //   orig order (API state)      posOrig  float4[N] (x,y,z,type)        velOrig float4[N] (vx,vy,vz,w)
-//   sorted order (per step)     sortedPos float4[N] (x,y,z,type)       sortedVel float4[N]     predPos float4[N]
+//   sorted order (per step)     sortedPos float4[N] (x,y,z,type)       sortedVel float4[N]     predPos float[3N] (x,y,z)
 //                               keys u32[N] (cell)  vals u32[N] (orig id)  backIndex u32[N] (orig -> sorted)
 //                               rho f32[N]   rp float2[N] (rhoPred, pressure)   acc / accP float4[N]
 //   neighbour map, tiled        nbr16 u16 (ids as offsets), nbrDist f32, nbrId i32 (rows nbr16 cannot hold):
@@ -49,7 +49,8 @@ struct SphDev {  // what the kernels see; passed by value
   int hasElastic;      // 0: membrane kernels are no-ops and are folded into integrate
   // buffers
   float4 *posOrig, *velOrig, *membDelta;
-  float4 *sortedPos, *sortedVel, *predPos, *acc, *accP;
+  float4 *sortedPos, *sortedVel, *acc, *accP;
+  float* predPos;    // predicted positions, packed (x, y, z): 3 floats per sorted particle
   uint32_t* elasticMask;  // bit k set: neighbour slot k holds an elastic particle (forces kernel -> membrane kernel)
   uint32_t* bndMask;  // bit k set: neighbour slot k holds a boundary particle (written by the forces kernel, read by integrate)
   float4* gatherRec; // 2 x ceil4(N) float4, groups of four particles [4 x (x,y,z,type)][4 x (v.xyz, rho)]: the forces kernel's neighbour gathers
