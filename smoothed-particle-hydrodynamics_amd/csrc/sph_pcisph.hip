@@ -7,6 +7,7 @@
 // Arithmetic keeps the reference's operand types and evaluation order: no FMA contraction, IEEE division/sqrt,
 // f32 denormals kept, f64 where sphFluid.cl uses double.
 #include "sph_common.h"
+#include "sph_fastmath.h"
 
 #define TYPE_OF(p4) ((int)(p4).w)
 typedef float f32x3 __attribute__((ext_vector_type(3)));
@@ -475,6 +476,38 @@ int sphk_integrate(sph_solver* s) {
 
 // ------------------------------------------------------------------ K12 pcisph_computePressureForceAcceleration
 // (sphFluid.cl:1101-1212). FUSE: 0 = alone, 1 = + next iteration's predictPositions, 2 = + integrate (last iteration).
+// One batch of PF_BATCH neighbours of the pressure-force sum. FAST: square root and the divisions by r through sph_fastmath.h;
+// returns false (wave-uniform) if any lane had an operand outside the ranges those sequences are valid in.
+template <bool FAST>
+__device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const float pi_, const float hq, const float4 (&xj)[PF_BATCH],
+                                         const float2 (&rpj)[PF_BATCH], const int (&jj)[PF_BATCH], float& rx, float& ry, float& rz,
+                                         const bool ownOk) {
+  bool ok = ownOk;
+#pragma unroll
+  for (int k = 0; k < PF_BATCH; k++) {
+    const float ex_ = xi.x - xj[k].x, ey_ = xi.y - xj[k].y, ez_ = xi.z - xj[k].z;
+    const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_;
+    float sq_;
+    if (FAST) ok = sph_sqrt_fast(d2_, &sq_) && ok;
+    else sq_ = sqrtf(d2_);
+    const float r = sq_ * d.simScale;  // == the stored neighborMap distance (sphFluid.cl:131-136,172), which is therefore not read
+    // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
+    // the numerator is selected first, so only one IEEE division is spent
+    const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
+    const float value = num / rpj[k].x;
+    const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
+    const bool use = jj[k] != -1 && r < d.hs;
+    const float ax_ = value * vx, ay_ = value * vy, az_ = value * vz;
+    float q_[3];
+    if (FAST) ok = sph_div3_by(ax_, ay_, az_, value, d.fastValueMin, r, q_) && ok;
+    else { q_[0] = ax_ / r; q_[1] = ay_ / r; q_[2] = az_ / r; }
+    rx = use ? rx + q_[0] : rx;
+    ry = use ? ry + q_[1] : ry;
+    rz = use ? rz + q_[2] : rz;
+  }
+  return !FAST || !__any(!ok);
+}
+
 template <int FUSE>
 __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblocks) {
   int id;
@@ -488,6 +521,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   }
   const float2 rpi = d.rp[id];  // (rho*, p) of this particle
   const float pi_ = rpi.y;
+  // precondition of the short division sequence (sph_fastmath.h): own coordinates not within 2^-4 of zero
+  const bool ownOk = sph_exp_in(xi.x, SPH_FAST_COORD_EXP_LO, 100) && sph_exp_in(xi.y, SPH_FAST_COORD_EXP_LO, 100) &&
+                     sph_exp_in(xi.z, SPH_FAST_COORD_EXP_LO, 100);
   const NbrTile t(d, id);
   float rx = 0.f, ry = 0.f, rz = 0.f;
   const float hq = d.hs * 0.25f;
@@ -520,19 +556,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
       xj[k] = d.sortedPos[jc];
       rpj[k] = d.rp[jc];
     }
-#pragma unroll
-    for (int k = 0; k < PF_BATCH; k++) {
-      const float ex_ = xi.x - xj[k].x, ey_ = xi.y - xj[k].y, ez_ = xi.z - xj[k].z;
-      const float r = sqrtf(ex_ * ex_ + ey_ * ey_ + ez_ * ez_) * d.simScale;  // == the stored neighborMap distance
-      // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
-      // the numerator is selected first, so only one IEEE division is spent
-      const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
-      const float value = num / rpj[k].x;
-      const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
-      const bool use = jj[k] != -1 && r < d.hs;
-      rx = use ? rx + value * vx / r : rx;
-      ry = use ? ry + value * vy / r : ry;
-      rz = use ? rz + value * vz / r : rz;
+    // The kernel is bound by its arithmetic: the IEEE square root and the three IEEE divisions by r take the short sequences of
+    // sph_fastmath.h, bit-identical inside their operand ranges; a batch in which any lane of the wave leaves those ranges is
+    // simply computed again with the compiler's sqrtf and `/` (same results for the lanes that were inside).
+    const float bx = rx, by = ry, bz = rz;
+    if (!pf_batch<true>(d, xi, pi_, hq, xj, rpj, jj, rx, ry, rz, ownOk)) {
+      rx = bx; ry = by; rz = bz;
+      pf_batch<false>(d, xi, pi_, hq, xj, rpj, jj, rx, ry, rz, true);
     }
   }
   const float scale = (float)(d.massGradW / (double)rpi.x);
