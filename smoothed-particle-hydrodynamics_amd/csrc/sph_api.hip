@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "sph_common.h"
+#include "sph_fastmath.h"
 
 static thread_local char g_err[512] = "";
 void sph_set_error(const char* fmt, ...) {
@@ -282,7 +283,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   d.cellMask = cfg->cellIdMask;
   d.h = cfg->h; d.cellSize = cfg->hashGridCellSize; d.cellSizeInv = cfg->hashGridCellSizeInv;
   d.simScale = cfg->simulationScale; d.simScaleInv = cfg->simulationScaleInv;
-  d.fastValueMin = 2.f * ldexpf(1.f, -100 + 4 + 24) / cfg->simulationScale;  // sph_fastmath.h: SPH_FAST_A_EXP_LO, SPH_FAST_COORD_EXP_LO
+  sph_fast_bounds(cfg->simulationScale, &d.fastD2Min, &d.fastD2Max, &d.fastValueMin);
   d.xmin = cfg->xmin; d.xmax = cfg->xmax; d.ymin = cfg->ymin; d.ymax = cfg->ymax; d.zmin = cfg->zmin; d.zmax = cfg->zmax;
   d.r0 = cfg->r0; d.mass = cfg->mass; d.rho0 = cfg->rho0; d.dt = cfg->timeStep; d.delta = cfg->delta;
   d.gravx = cfg->gravity_x; d.gravy = cfg->gravity_y; d.gravz = cfg->gravity_z;

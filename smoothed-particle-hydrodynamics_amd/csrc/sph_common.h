@@ -42,7 +42,7 @@ struct SphDev {  // what the kernels see; passed by value
   double massGradW;    // ((double)mass)*gradWspikyCoefficient (sphFluid.cl:1194)
   double del2W;        // del2WviscosityCoefficient
   double closeR;       // 0.5*(hScaled/2) as the double the comparison at sphFluid.cl:1166 uses
-  float fastValueMin;  // smallest |value| of k_pressure_force's short division path (sph_fastmath.h)
+  float fastValueMin, fastD2Min, fastD2Max;  // operand bounds of k_pressure_force's short division / square-root path (sph_fast_bounds)
   float closeRf;       // the same test on floats: (double)r < closeR <=> r < closeRf (smallest float >= closeR)
   int rangeLo, rangeHi;  // a launch serves the sorted particles of cells [rangeLo, rangeHi): all of them ([0, G)) except in
                          // slab mode, where ghost layers that a stage's results are not needed on are skipped (sph_api.hip)

@@ -488,7 +488,7 @@ __device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const
     const float ex_ = xi.x - xj[k].x, ey_ = xi.y - xj[k].y, ez_ = xi.z - xj[k].z;
     const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_;
     float sq_;
-    if (FAST) ok = sph_sqrt_fast(d2_, &sq_) && ok;
+    if (FAST) ok = sph_sqrt_fast(d2_, d.fastD2Min, d.fastD2Max, &sq_) && ok;  // (the bounds also keep r inside the division's range)
     else sq_ = sqrtf(d2_);
     const float r = sq_ * d.simScale;  // == the stored neighborMap distance (sphFluid.cl:131-136,172), which is therefore not read
     // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
@@ -499,7 +499,7 @@ __device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const
     const bool use = jj[k] != -1 && r < d.hs;
     const float ax_ = value * vx, ay_ = value * vy, az_ = value * vz;
     float q_[3];
-    if (FAST) ok = sph_div3_by(ax_, ay_, az_, value, d.fastValueMin, r, q_) && ok;
+    if (FAST) ok = sph_div3_by<false>(ax_, ay_, az_, value, d.fastValueMin, r, q_) && ok;
     else { q_[0] = ax_ / r; q_[1] = ay_ / r; q_[2] = az_ / r; }
     rx = use ? rx + q_[0] : rx;
     ry = use ? ry + q_[1] : ry;

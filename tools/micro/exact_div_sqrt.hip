@@ -35,37 +35,39 @@ __global__ void k_check(uint64_t seed, int iters, unsigned long long* bad, unsig
   uint64_t s = seed * 0x100000001b3ull + (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9e3779b97f4a7c15ull;
   unsigned long long nb = 0, ns = 0;
   for (int it = 0; it < iters; it++) {
-    // division: r, value in the guarded ranges (and a little beyond, to exercise the guard), components up to r in magnitude
-    const float r = rnd_float(s, SPH_FAST_R_EXP_LO - 2, SPH_FAST_R_EXP_HI + 2, false);
-    const float value = (rng(s) & 63u) == 0 ? 0.f : rnd_float(s, -80, 62, true);
+    // the kernel's data flow: a length scale, the bounds the host derives from it, d2 -> r = sqrt(d2) * scale -> numerators value * v_k
+    const float scale = rnd_float(s, -26, 0, false);
+    float d2Min, d2Max, valueMin;
+    sph_fast_bounds(scale, &d2Min, &d2Max, &valueMin);
+    const float x = rnd_float(s, SPH_FAST_S_EXP_LO - 4, SPH_FAST_S_EXP_HI + 3, false);  // also beyond both ends of the bounds
+    float sq;
+    const bool fs = sph_sqrt_fast(x, d2Min, d2Max, &sq);
+    const float wantS = sqrtf(x);
+    if (!fs) ns++;
+    else if (__float_as_uint(sq) != __float_as_uint(wantS)) { if (nb == 0) { example[0] = x; example[1] = 0.f; example[2] = sq; example[3] = wantS; } nb++; }
+    if (!fs) continue;  // (the kernel recomputes such a batch with the compiler's code)
+    const float r = wantS * scale;
+    const float value = (rng(s) & 63u) == 0 ? 0.f : rnd_float(s, -120, 62, true);
     float v[3];
     for (int c = 0; c < 3; c++) {
       const uint32_t pick = rng(s) & 15u;
-      const int down = (int)(rng(s) % 70u);  // the component is up to 2^69 times shorter than r (numerators down to 2^-150: denormal)
+      const int down = (int)(rng(s) % 70u);  // the component is up to 2^69 times shorter than r (numerators down to denormals)
       v[c] = pick == 0 ? 0.f : rnd_float(s, 0, 0, true) * r * __uint_as_float((uint32_t)(127 - down) << 23) * (pick == 1 ? 1.f : 0.999f);
     }
     float q[3];
-    bool fast = sph_div3_by(value * v[0], value * v[1], value * v[2], value, 0x1p-80f, r, q);
+    bool fast = sph_div3_by<false>(value * v[0], value * v[1], value * v[2], value, valueMin, r, q);
     for (int c = 0; c < 3; c++) {  // the caller's precondition: numerators zero or at least 2^SPH_FAST_A_EXP_LO
       const float a = fabsf(value * v[c]);
       if (a != 0.f && a < __uint_as_float((uint32_t)(SPH_FAST_A_EXP_LO + 127) << 23)) fast = false;
     }
-    if (!fast) ns++;
+    if (!fast) { ns++; continue; }
     for (int c = 0; c < 3; c++) {
       const float a = value * v[c];
       const float want = a / r;
-      const float got = fast ? q[c] : want;
       // (+0 and -0 are interchangeable for the kernel: the terms are added to sums that are never -0)
-      const bool same = __float_as_uint(got) == __float_as_uint(want) || (got == 0.f && want == 0.f);
-      if (!same) { if (nb == 0) { example[0] = a; example[1] = r; example[2] = got; example[3] = want; } nb++; }
+      const bool same = __float_as_uint(q[c]) == __float_as_uint(want) || (q[c] == 0.f && want == 0.f);
+      if (!same) { if (nb == 0) { example[0] = a; example[1] = r; example[2] = q[c]; example[3] = want; } nb++; }
     }
-    // square root
-    const float x = rnd_float(s, SPH_FAST_S_EXP_LO - 2, SPH_FAST_S_EXP_HI + 2, false);
-    float sq;
-    const bool fs = sph_sqrt_fast(x, &sq);
-    if (!fs) ns++;
-    const float wantS = sqrtf(x);
-    if (fs && __float_as_uint(sq) != __float_as_uint(wantS)) { if (nb == 0) { example[0] = x; example[1] = 0.f; example[2] = sq; example[3] = wantS; } nb++; }
   }
   if (nb) atomicAdd(bad, nb);
   if (ns) atomicAdd(slow, ns);
@@ -82,7 +84,7 @@ int main(int argc, char** argv) {
   unsigned long long bad, slow; float ex[4];
   CHECK(hipMemcpy(&bad, dBad, 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&slow, dSlow, 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ex, dEx, 16, hipMemcpyDeviceToHost));
   const double n = (double)rounds * blocks * threads * iters;
-  printf("%.3g operand sets (3 quotients + 1 square root each): %llu results differ from the IEEE expansions; %llu sets took the guarded slow path\n", n, bad, slow);
+  printf("%.3g operand sets (a square root, then 3 quotients by r = root * scale): %llu results differ from the IEEE expansions; %llu times a guard sent the set to the slow path\n", n, bad, slow);
   if (bad) printf("first difference: a or x = %a, r = %a, got %a, want %a\n", ex[0], ex[1], ex[2], ex[3]);
   return bad ? 1 : 0;
 }
