@@ -493,7 +493,8 @@ __device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const
     const float r = sq_ * d.simScale;  // == the stored neighborMap distance (sphFluid.cl:131-136,172), which is therefore not read
     // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
     // the numerator is selected first, so only one IEEE division is spent
-    const float num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
+    float num = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
+    if (__any(r < d.closeRf)) num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : num;  // (pairs closer than h/4: rare, so wave-uniformly skipped)
     const float value = num / rpj[k].x;
     const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
     const bool use = jj[k] != -1 && r < d.hs;
