@@ -17,13 +17,17 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 delay = float(sys.argv[2]) * 1e-6 if len(sys.argv) > 2 else 150e-6
 overlap = os.environ.get("SPHMI_SLAB_OVERLAP", "1") != "0"
 world = 3
-sc = scenes.liquid_box((50.0, 50.0, 50.0 * world), (100, 100, 100 * world), mask=0xffffffff)
+# default: three slabs of the config #2 column (weak scaling). SPHMI_SLAB_BOX="78,50,176.25" SPHMI_SLAB_LATTICE="160,100,375" is
+# three eighths of the config #4 box: the middle slab then carries what an interior rank of `bench.py --gpus 8` carries.
+BOX = tuple(float(v) for v in os.environ.get("SPHMI_SLAB_BOX", "50,50,%g" % (50.0 * world)).split(","))
+LAT = tuple(int(v) for v in os.environ.get("SPHMI_SLAB_LATTICE", "100,100,%d" % (100 * world)).split(","))
+sc = scenes.liquid_box(BOX, LAT, mask=0xffffffff)
 n_global = sc["cfg"].particleCount
 layers = S.particle_layers(sc["position"], sc["cfg"])
 cuts = S.balanced_cuts(layers, world)
 backs = []
 for r in range(world):
-    cfg = scenes.liquid_box((50.0, 50.0, 50.0 * world), (2, 2, 2), mask=0xffffffff)["cfg"]  # a config object per solver
+    cfg = scenes.liquid_box(BOX, (2, 2, 2), mask=0xffffffff)["cfg"]  # a config object per solver
     slab = S.make_slab(cuts, r, world, n_global)
     idx = S.local_indices(layers, slab)
     backs.append(S.HipSlabBackend(cfg, sc["position"][idx], sc["velocity"][idx], idx, slab))
