@@ -437,6 +437,10 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
     for (int i = 0; i < 4; i++) pHi[i] = pLo[i];
     if (quadLane == 0) atomicAdd(&dbg[0], 1u);
   }
+#ifdef DIAG_NO_WALK  // timing only: nothing is walked (every list stays empty)
+#pragma unroll
+  for (int i = 0; i < 4; i++) pHi[i] = pLo[i];
+#endif
   FN_STAMP(4)
 
   // ---- 1. single walk with the cheap filter; r_max covers pass 0 (h) and every possible pass-1 radius (<= 31h/30).
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
         X = *reinterpret_cast<const f32x4*>(&sh.x[a + 8]);
         Y = *reinterpret_cast<const f32x4*>(&sh.y[a + 8]);
         Z = *reinterpret_cast<const f32x4*>(&sh.z[a + 8]);
-        __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from sinking the reads to the end of the trip, next to their use)
+        __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from sinking the reads to the end of the trip, next to their use; without: same time)
         FN_TEST(Xb, Yb, Zb)
         Xb = *reinterpret_cast<const f32x4*>(&sh.x[a + 12]);
         Yb = *reinterpret_cast<const f32x4*>(&sh.y[a + 12]);
@@ -524,6 +528,11 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
 #undef FN_TEST
 #undef FN_FLUSH
   FN_STAMP(5)
+#ifdef DIAG_NO_REPLAY  // timing only: the lists are walked and then dropped (a 1-entry list per lane keeps the walk alive)
+  { const int keep = min(cnt, 1); cnt = keep;
+#pragma unroll
+    for (int i = 0; i < 4; i++) segEnd[i] = min(segEnd[i], keep); }
+#endif
   int over = cnt > FN_LIST_CAP ? 1 : 0;
   over |= grp_other_half(over);  // all lanes of the particle take part
   over |= grp_other_pair(over);
