@@ -275,6 +275,23 @@ def test_config4_sixteen_million_box_properties():
     assert scenes.bits_equal(rho.astype(np.float32), hip.read_density_buffer())
 
 
+def test_config4_sixteen_million_box_full_steps_against_oracle():
+    """BASELINE config #4 at full size, FULL steps, against the oracle itself (16 host threads, ~2 s per step): positions, velocities,
+    densities and pressures of all 16,507,704 particles after each of three fused steps, bit for bit. (The other buffers at this size are
+    covered by the properties test above and, word for word, by the 1 M wide-mode test below.)"""
+    sc = scenes.liquid_box((78.0, 50.0, 470.0), (160, 100, 1000), mask=0xffffffff)
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16)
+    for it in range(3):
+        hip.step(it)
+        ora.step()
+        assert scenes.bits_equal(hip.read_position_buffer(), ora.buffer("position").reshape(-1, 4)[:N]), it
+        assert scenes.bits_equal(hip.read_velocity_buffer(), ora.buffer("velocity").reshape(-1, 4)[:N]), it
+        assert scenes.bits_equal(hip.read_density_buffer(), ora.buffer("rho").reshape(-1)[:N]), it
+        assert scenes.bits_equal(hip.buffer("pressure").reshape(-1)[:N], ora.buffer("pressure").reshape(-1)[:N]), it
+    ora.close()
+
+
 def test_wide_mode_million_particles_full_steps_against_oracle():
     """Wide cell ids at scale, FULL steps: 1.07 M particles on a grid of 152,561 declared cells (3 radix passes, ids > 2^16),
     three fused steps compared with the oracle word for word in every buffer (search structures, neighbour ids and distances,
