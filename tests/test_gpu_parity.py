@@ -375,6 +375,23 @@ def test_config5_sixty_four_million_dam_break_properties():
     assert abs(vel[:nl, 1].astype(np.float64).mean() / g_dt - 1.0) < 1e-3
 
 
+def test_config5_sixty_four_million_full_steps_against_oracle():
+    """BASELINE config #5 at full size against the oracle itself (65,469,208 particles; ~40 GB of host memory and ~10 s per step for
+    the oracle on 16 threads): positions, velocities, densities and pressures after each of two fused steps, bit for bit."""
+    sc = scenes.liquid_box((240.0, 200.0, 310.0), (250, 400, 640), mask=0xffffffff)
+    N = sc["cfg"].particleCount
+    assert N == 65469208
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16)
+    for it in range(2):
+        hip.step(it)
+        ora.step()
+        assert scenes.bits_equal(hip.read_position_buffer(), ora.buffer("position").reshape(-1, 4)[:N]), it
+        assert scenes.bits_equal(hip.read_velocity_buffer(), ora.buffer("velocity").reshape(-1, 4)[:N]), it
+        assert scenes.bits_equal(hip.read_density_buffer(), ora.buffer("rho").reshape(-1)[:N]), it
+        assert scenes.bits_equal(hip.buffer("pressure").reshape(-1)[:N], ora.buffer("pressure").reshape(-1)[:N]), it
+    ora.close()
+
+
 def test_two_solvers_in_one_process():
     """Two solvers side by side in one process (own streams; on a second device too where the box has one): the dynamic-LDS opt-in
     of the search kernel is per device, and neither solver disturbs the other's state."""
