@@ -1,11 +1,13 @@
-"""One-off (not collected by pytest): config #2 at full size, 100 steps on the GPU and on the oracle, every 25 steps all
-positions / velocities / neighbour ids compared bit for bit.   python tests/long_run_parity.py [steps]"""
+"""One-off (not collected by pytest): config #2 (or, with a second argument "config4", the 16.5 M-particle box of config #4) at full
+size, 100 steps on the GPU and on the oracle, every 25 steps all positions / velocities / neighbour ids compared bit for bit.
+python tests/long_run_parity.py [steps] [config2|config4]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import scenes
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-sc = scenes.liquid_box((50.0, 50.0, 50.0), (100, 100, 100), mask=0xffff)
+big = len(sys.argv) > 2 and sys.argv[2] == "config4"
+sc = scenes.liquid_box((78.0, 50.0, 470.0), (160, 100, 1000), mask=0xffffffff) if big else scenes.liquid_box((50.0, 50.0, 50.0), (100, 100, 100), mask=0xffff)
 N = sc["cfg"].particleCount
 hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=int(os.environ.get("ORACLE_THREADS", "16")))
 t0 = time.time()
