@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — particle-steps/s of the PCISPH step path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL. Either the driver starts the ranks (`python -m torch.distributed.run ... bench.py
+--gpus N`: WORLD_SIZE is set, this file is a rank) or this file does: called from a plain shell with --gpus N > 1 and no
+WORLD_SIZE it starts N fresh child processes with torch.distributed.run BEFORE touching any GPU, relays rank 0's JSON
+line and exits with the children's status (a process that has initialised the GPU is never re-executed).
 
 A "step" is one full simulationStep() (owPhysicsFluidSimulator.cpp:79-149: neighbour search + PCISPH predict-correct
 loop + integration) of BASELINE config #4, the 16M-particle pure-liquid box of SURVEY §8(d) (N = 16,507,704 including
@@ -15,12 +20,18 @@ Rank 0 prints ONE JSON line. Besides the contract fields it carries
   cpu_baseline  the CPU restatement (oracle/, "port") timed on this box's host cores on the same scene, few steps
   stages_ms     mean device time per stage per step (HIP events), findNeighbors reported as time
   stages_frac   per stage: algorithmic bytes (lean layout) / time / 8 TB/s
-  config2_1M_cube   the 1M-particle cube of config #2 as an extra block (N = 1 only): value, ms/step, stages
+  lib           path, sha256 and sph_build_info() of the libsphmi.so that ran (a diagnostic build is refused)
+  config2_1M_cube, config3_worm, evolved_dam_break   extra blocks, N = 1 only and outside `value`: the 1M cube of config #2;
+                the worm scene of config #3 (elastic matter, membranes, muscles on); a 0.77 M-particle liquid column after
+                1,500 steps of collapse (disordered state: the exact-walk counters of findNeighbors are reported)
+  rccl_ranks, devices, halo   (N > 1) world size as the process group reports it, each rank's device, per-rank exchange figures
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,11 +46,12 @@ WORKLOADS = {
     # name: (box in h, liquid lattice, cell id mask)
     "config2_1M_cube": ((50.0, 50.0, 50.0), (100, 100, 100), 0xffff),
     "tiny": ((8.0, 8.0, 8.0), (12, 10, 12), 0xffff),
+    "tiny_long": ((8.0, 8.0, 60.0), (12, 10, 110), 0xffffffff),  # 30 cell layers: the smallest box two slabs fit in (tests)
     "cube_4M": ((80.0, 80.0, 80.0), (160, 160, 160), 0xffffffff),
     "config4_16M_box": ((78.0, 50.0, 470.0), (160, 100, 1000), 0xffffffff),  # SURVEY 8(d) config #4, strong scaling
     "config5_64M_dambreak": ((240.0, 200.0, 310.0), (250, 400, 640), 0xffffffff),  # liquid column at low x
 }
-
+DAM_BREAK = ((120.0, 50.0, 50.0), (80, 90, 100), 0xffffffff)  # extra block: 0.72 M liquid particles in a column at low x
 
 DEFAULT_WORKLOAD = "config4_16M_box"
 
@@ -79,7 +91,116 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def main():
+# ----------------------------------------------------------------------------------------------- liveness
+# Every rank reports progress ("beats"); a rank that is silent for SPHMI_WATCHDOG_S seconds (default 120) ends the run with a
+# non-zero status instead of hanging until somebody's outer limit: inside each rank a daemon thread checks the rank's own last
+# beat (covers ranks started by the driver's torch.distributed.run), and the self-launcher checks every rank's heartbeat file.
+WATCHDOG_S = float(os.environ.get("SPHMI_WATCHDOG_S", "120"))
+_last_beat = [time.monotonic(), "start"]
+
+
+def beat(phase):
+    _last_beat[0], _last_beat[1] = time.monotonic(), phase
+    d = os.environ.get("SPHMI_HEARTBEAT_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, "rank%s" % os.environ.get("RANK", "0")), "w") as f:
+                f.write(phase)
+        except OSError:
+            pass
+
+
+def start_rank_watchdog(rank):
+    def run():
+        while True:
+            time.sleep(min(5.0, max(0.2, WATCHDOG_S / 4)))
+            idle = time.monotonic() - _last_beat[0]
+            if idle > WATCHDOG_S:
+                sys.stderr.write("bench.py watchdog: rank %d silent for %.0f s in phase '%s' — giving up\n" % (rank, idle, _last_beat[1]))
+                sys.stderr.flush()
+                os._exit(3)
+    threading.Thread(target=run, daemon=True).start()
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 from a plain shell: N fresh ranks under torch.distributed.run. Nothing in THIS process touches a GPU (torch
+    is not even imported); the children are a new process group so that a hung run can be ended as a whole."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    hb = tempfile.mkdtemp(prefix="sphmi_bench_hb_")
+    env = dict(os.environ, SPHMI_HEARTBEAT_DIR=hb, SPHMI_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True, bufsize=1)
+    lines = []
+
+    def pump():
+        for line in proc.stdout:
+            if line.startswith('{"metric"'):
+                lines.append(line)
+            else:  # anything else the ranks or the launcher print is not the result line
+                sys.stderr.write(line)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    started = time.monotonic()
+    hung = None
+    while proc.poll() is None:
+        time.sleep(0.5)
+        now = time.time()
+        for r in range(args.gpus):
+            f = os.path.join(hb, "rank%d" % r)
+            try:
+                idle, phase = now - os.path.getmtime(f), open(f).read()
+            except OSError:
+                idle, phase = time.monotonic() - started, "not started"
+            if idle > WATCHDOG_S + 10.0:  # (the rank's own watchdog fires first; this one covers a rank that cannot even do that)
+                hung = (r, idle, phase)
+        if hung:
+            sys.stderr.write("bench.py: rank %d silent for %.0f s in phase '%s': ending the run\n" % hung)
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                proc.wait(timeout=10)
+            except Exception:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+            break
+    rc = proc.wait()
+    t.join(timeout=5)
+    for f in os.listdir(hb):
+        os.unlink(os.path.join(hb, f))
+    os.rmdir(hb)
+    if hung:
+        return 3
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: expected one result line from rank 0, got %d\n" % len(lines))
+        return 4
+    for line in lines:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    return rc
+
+
+def lib_identity():
+    """Path, sha256 and build info of the libsphmi.so this process loaded."""
+    import sphmi
+    h = hashlib.sha256()
+    with open(sphmi.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return {"path": os.path.relpath(sphmi.LIB_PATH, ROOT), "sha256": h.hexdigest(), "build": sphmi.build_info(),
+            "selected_by_SPHMI_LIB": bool(os.environ.get("SPHMI_LIB"))}
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -89,37 +210,68 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=-1,
                     help="steps of the CPU baseline (default: ~10 s of work on 16 cores, e.g. 4 at 16.5 M; 0 = skip)")
     ap.add_argument("--no-stage-pass", action="store_true", help="skip the second, per-stage-timed pass")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config #2 extra block")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra blocks (config #2, config #3, evolved dam break)")
+    ap.add_argument("--allow-diagnostic-lib", action="store_true", help="run although SPHMI_LIB names a timing-only (invalid-results) build")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1 only: launcher, rendezvous, cuts and per-rank scene slices, no solver (needs no GPU; tests)")
+    return ap.parse_args(argv)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
+    rank_main(args)
+
+
+def rank_main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d: start it with --nproc-per-node %d (or without a launcher)" % (args.gpus, world, args.gpus))
+    beat("imports")
+    if world > 1:
+        start_rank_watchdog(rank)
 
     import numpy as np
     import torch
     import scenes
     import sphmi
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     dist = None
+    backend_name = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # SPHMI_DIST_BACKEND=gloo lets several ranks share one card (functional rehearsal on a 1-GPU box: host-staged halo)
-        backend_name = os.environ.get("SPHMI_DIST_BACKEND", "nccl")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        # SPHMI_DIST_BACKEND=gloo lets several ranks share one card (functional rehearsal on a 1-GPU box: host-staged halo);
+        # it is also what a run with fewer cards than ranks falls back to (RCCL refuses two ranks on one device)
+        ndev = torch.cuda.device_count()
+        backend_name = os.environ.get("SPHMI_DIST_BACKEND") or ("nccl" if ndev >= world else "gloo")
+        beat("rendezvous (%s)" % backend_name)
+        if not args.dry_run:
+            local_rank = local_rank % max(1, ndev)
+            torch.cuda.set_device(local_rank)
         if backend_name == "nccl":  # bind the communicator to this rank's GPU explicitly (one process per GPU)
             dist.init_process_group(backend_name, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend_name, rank=rank, world_size=world)
         dist.barrier()  # creates the communicator with every rank present before the first point-to-point exchange
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: libsphmi has no CPU path")
-    torch.cuda.set_device(local_rank)
+        beat("rendezvous done")
+    comm_dev = "cuda" if backend_name == "nccl" else "cpu"
+    if args.dry_run:
+        if world == 1:
+            sys.exit("--dry-run is for --gpus N > 1")
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: libsphmi has no CPU path")
+        torch.cuda.set_device(local_rank)
+        lib = lib_identity()
+        if "DIAG" in lib["build"] and not args.allow_diagnostic_lib:
+            sys.exit("bench.py: %s is a diagnostic build (%s): its results are invalid; pass --allow-diagnostic-lib to time it anyway"
+                     % (lib["path"], lib["build"]))
 
     strong = args.workload != "weak"
     if not strong:
@@ -130,30 +282,52 @@ def main():
         if world > 1:
             mask = 0xffffffff  # the slab decomposition needs wide cell ids
         workload_name = args.workload
-    sc = scenes.liquid_box(box, lattice, mask=mask)
-    cfg = sc["cfg"]
-    cfg.device = local_rank
-    stream = torch.cuda.Stream(device=local_rank)
-    cfg.stream = stream.cuda_stream  # the solver launches on this stream; torch events below are recorded on it
-    N = cfg.particleCount  # global particle count
+
     decomposition = None
+    stream = None
+    beat("scene")
     if world > 1:
+        # Every rank builds only ITS slice of the scene (own layers + ghost layers) from the generator, after cutting the box with
+        # the per-layer histogram — no rank ever holds the 16.5 M-particle arrays (N x 528 MB of host copies otherwise).
         from sphmi import slab as S
-        layers = S.particle_layers(sc["position"], cfg)
-        cuts = S.balanced_cuts(layers, world)
+        cfg = scenes.liquid_box_config(box, mask=mask)
+        nl, nb = sphmi.box_counts(cfg, *lattice)
+        N = nl + nb
+        hist = sphmi.box_layer_histogram(cfg, *lattice)
+        occupied = np.flatnonzero(hist)
+        lo_layer = int(occupied[0])
+        cuts = S.balanced_cuts_hist(hist[lo_layer:int(occupied[-1]) + 1], lo_layer, world)
         slab = S.make_slab(cuts, rank, world, N)
-        idx = S.local_indices(layers, slab)
-        backend = S.HipSlabBackend(cfg, sc["position"][idx], sc["velocity"][idx], idx, slab)
+        own_lo = slab.layerLo - slab.ghostLayers if slab.hasLower else S.OPEN_LO
+        own_hi = slab.layerHi + slab.ghostLayers if slab.hasUpper else S.OPEN_HI
+        pos_l, vel_l, gid_l = sphmi.generate_box_slice(cfg, *lattice, own_lo, own_hi)
+        beat("scene slice: %d particles" % gid_l.size)
+        if args.dry_run:
+            return dry_run_report(args, np, torch, dist, S, cfg, slab, pos_l, gid_l, N, rank, world, workload_name, backend_name)
+        cfg.device = local_rank
+        stream = torch.cuda.Stream(device=local_rank)
+        cfg.stream = stream.cuda_stream
+        backend = S.HipSlabBackend(cfg, pos_l, vel_l, gid_l, slab)
+        del pos_l, vel_l
         decomposition = S.SlabDecomposition(backend, rank, world, dist)
         solver = backend.solver
+        sc = None
 
         class _Stepper:  # step + halo exchange
             def step(self, it):
                 decomposition.step(it)
+                beat("step %d" % it)
         stepper = _Stepper()
     else:
+        sc = scenes.liquid_box(box, lattice, mask=mask)
+        cfg = sc["cfg"]
+        cfg.device = local_rank
+        stream = torch.cuda.Stream(device=local_rank)
+        cfg.stream = stream.cuda_stream  # the solver launches on this stream; torch events below are recorded on it
+        N = cfg.particleCount  # global particle count
         solver = sphmi.owHIPSolver(cfg, sc["position"], sc["velocity"])
         stepper = solver
+    beat("solver ready")
 
     def barrier():
         torch.cuda.synchronize()
@@ -165,6 +339,7 @@ def main():
     for _ in range(args.warmup):
         stepper.step(it); it += 1
     barrier()
+    beat("warm-up done")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
@@ -174,9 +349,10 @@ def main():
         ev1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
+    beat("timed region done")
     dev_ms = ev0.elapsed_time(ev1)
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([wall], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     ms_per_step = wall * 1e3 / args.steps
@@ -202,16 +378,20 @@ def main():
                         "traffic": None, "avg_launch_us": round(d_ms / d_cnt * 1e3, 2),
                         "bytes_per_launch": n_local * DENSITY_BYTES_PER_PARTICLE}
             # HBM bytes from the committed rocprofv3 PMC passes of this workload (profiles/README.md) — NOT measured in this
-            # run: counters cannot be read from inside the process
+            # run (counters cannot be read from inside the process), and only quoted while the kernel sources are the ones the
+            # passes were taken on
             traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
             if os.path.exists(traffic_file) and world == 1:
                 tr = json.load(open(traffic_file))
-                if tr.get("workload") == workload_name:
-                    roofline["traffic"] = tr.get("hbm_bytes_per_launch")
-                elif workload_name in tr.get("other_workloads", {}):
-                    roofline["traffic"] = tr["other_workloads"][workload_name]["hbm_bytes_per_launch"]
-                if roofline["traffic"] is not None:
-                    roofline["traffic_source"] = "profiles/density_traffic.json (committed rocprofv3 PMC passes; not this run)"
+                entry = tr if tr.get("workload") == workload_name else tr.get("other_workloads", {}).get(workload_name)
+                if entry is not None:
+                    current = density_sources_sha()
+                    if tr.get("kernel_sources_sha256") in (None, current):
+                        roofline["traffic"] = entry.get("hbm_bytes_per_launch")
+                        roofline["traffic_source"] = "profiles/density_traffic.json (committed rocprofv3 PMC passes; not this run)"
+                    else:
+                        roofline["traffic_source"] = ("profiles/density_traffic.json is stale: measured on other kernel sources (%s..., now %s...)"
+                                                      % (tr["kernel_sources_sha256"][:12], current[:12]))
         # per stage: algorithmic bytes of all its launches in one step / its time / 8 TB/s (pure-liquid scenes)
         sort_passes = solver.step_sort_passes()
         algo = dict(STAGE_ALGO_BYTES, sort=24 * sort_passes)  # 24 B per particle and radix pass (2 or 3 passes)
@@ -223,6 +403,7 @@ def main():
             moved = sum(algo[k] for k in stages_ms if k in algo)
             stages_frac["whole_step_bytes_moved"] = moved
             stages_frac["whole_step_moved"] = round(n_local * moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    beat("stage pass done")
 
     # Multi-GPU sanity after the timed region (outside `value`): the ranks' owned sets must still partition the particles and
     # every owned particle must be finite — a silent halo failure would show here.
@@ -231,23 +412,24 @@ def main():
         pos_l, vel_l, gid_l, owned_l = solver.slab_read()
         m = owned_l.astype(bool)
         stats = torch.tensor([float(m.sum()), float(np.isfinite(pos_l[m]).all() and np.isfinite(vel_l[m]).all()),
-                              float(gid_l[m].astype(np.float64).sum())], dtype=torch.float64,
-                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                              float(gid_l[m].astype(np.float64).sum())], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         partition_ok = bool(int(stats[0].item()) == N and int(stats[1].item()) == world
                             and abs(stats[2].item() - N * (N - 1) / 2.0) < 0.5)  # every global id exactly once
 
-    per_rank = None  # every rank's local particle count, bytes sent and host time spent in the exchange (waits included)
+    per_rank = None  # every rank's local particle count, bytes sent, host time spent in the exchange (waits included), device
     if decomposition is not None:
-        mine = torch.tensor([float(solver.N), float(decomposition.bytes_sent), float(getattr(decomposition, "exchange_seconds", 0.0))],
-                            dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        mine = torch.tensor([float(solver.N), float(decomposition.bytes_sent), float(getattr(decomposition, "exchange_seconds", 0.0)),
+                             float(torch.cuda.current_device())], dtype=torch.float64, device=comm_dev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank = np.stack([g.cpu().numpy() for g in gathered])
 
     # SURVEY 8(d) extras, single GPU only and outside `value`: per-step p50 from one event pair per step, and the step
-    # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step).
-    p50_ms, readback_ms = None, None
+    # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step,
+    # owPhysicsFluidSimulator.cpp:115) — waited for like the reference does, and started asynchronously so that the copy
+    # runs under the next step (sph_read_position_async; the data is complete after the final wait).
+    p50_ms, readback_ms, readback_blocking_ms = None, None, None
     if world == 1:
         k3 = max(5, min(args.steps, 50))
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(k3 + 1)]
@@ -260,12 +442,24 @@ def main():
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
         p50_ms = per_step[len(per_step) // 2]
         host_pos = np.empty((N, 4), np.float32)
+        solver.read_position_buffer_async(host_pos)  # (page-locks host_pos once, outside the timed loop)
+        solver.wait_position_buffer()
         solver.synchronize()
         r0 = time.perf_counter()
         for _ in range(k3):
             stepper.step(it); it += 1
-            solver.read_position_buffer(host_pos)
+            solver.read_position_buffer_async(host_pos)
+        solver.wait_position_buffer()
+        solver.synchronize()
         readback_ms = (time.perf_counter() - r0) * 1e3 / k3
+        kb = max(3, k3 // 5)
+        r0 = time.perf_counter()
+        for _ in range(kb):
+            stepper.step(it); it += 1
+            solver.read_position_buffer(host_pos)
+        readback_blocking_ms = (time.perf_counter() - r0) * 1e3 / kb
+        del host_pos
+    beat("read-back pass done")
 
     # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
     cpu = None
@@ -299,34 +493,15 @@ def main():
         cpu["single_thread_value"] = round(sc1["cfg"].particleCount * n1 / c1, 1)
         cpu["single_thread_sample"] = "%d steps of the %d-particle cube of config #2, 1 thread" % (n1, sc1["cfg"].particleCount)
 
-    # extra block: BASELINE config #2 (1M cube, reference-exact 16-bit cell ids), GPU only, outside `value`
-    extra = None
-    if rank == 0 and world == 1 and not args.no_extra and workload_name != "config2_1M_cube":
+    # extra blocks, GPU only, N = 1 only, outside `value`
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra:
         solver.close()
-        b2, l2, m2 = WORKLOADS["config2_1M_cube"]
-        sc2 = scenes.liquid_box(b2, l2, mask=m2)
-        sc2["cfg"].device = local_rank
-        sc2["cfg"].stream = stream.cuda_stream
-        s2 = sphmi.owHIPSolver(sc2["cfg"], sc2["position"], sc2["velocity"])
-        n2 = sc2["cfg"].particleCount
-        for i in range(5):
-            s2.step(i)
-        torch.cuda.synchronize()
-        k = 50
-        e0 = time.perf_counter()
-        for i in range(k):
-            s2.step(5 + i)
-        torch.cuda.synchronize()
-        w2 = time.perf_counter() - e0
-        s2.set_stage_timing(True)
-        s2.reset_stage_times()
-        for i in range(20):
-            s2.step(55 + i)
-        st2 = s2.stage_times()
-        s2.set_stage_timing(False)
-        extra = {"particles": n2, "cell_ids": "ref16", "steps": k, "ms_per_step": round(w2 * 1e3 / k, 4),
-                 "value": round(n2 * k / w2, 1), "stages_ms": {a: round(ms / 20, 5) for a, (ms, cnt) in st2.items() if cnt}}
-        s2.close()
+        sc = None
+        if workload_name != "config2_1M_cube":
+            extra["config2_1M_cube"] = extra_config2(scenes, sphmi, torch, local_rank, stream)
+        extra["config3_worm"] = extra_worm(np, sphmi, torch, local_rank, stream)
+        extra["evolved_dam_break"] = extra_dam_break(np, scenes, sphmi, torch, local_rank, stream)
 
     if rank == 0:
         out = {
@@ -342,23 +517,166 @@ def main():
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "ms_per_step_p50": None if p50_ms is None else round(p50_ms, 4),
             "ms_per_step_with_position_readback": None if readback_ms is None else round(readback_ms, 4),
+            "ms_per_step_with_blocking_position_readback": None if readback_blocking_ms is None else round(readback_blocking_ms, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms, "stages_frac": stages_frac,
-            "radix_sort_passes": sort_passes,
+            "radix_sort_passes": sort_passes, "lib": lib,
         }
-        if extra:
-            out["config2_1M_cube"] = extra
+        out.update(extra)
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         if decomposition is not None:
+            out["dist_backend"] = backend_name
+            out["rccl_ranks"] = dist.get_world_size() if backend_name == "nccl" else 0
+            out["devices"] = per_rank[:, 3].astype(int).tolist()
             out["halo"] = {"local_particles_per_rank": per_rank[:, 0].astype(int).tolist(),
                            "bytes_sent_per_step_per_rank": (per_rank[:, 1] / max(1, it)).astype(int).tolist(),
                            "exchange_host_ms_per_step_per_rank": [round(v * 1e3 / max(1, it), 4) for v in per_rank[:, 2]],
                            "p2p_groups_per_step_rank0": round(decomposition.transfers / max(1, it), 3),
                            "owned_sets_partition_all_particles": partition_ok}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    beat("done")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def density_sources_sha():
+    """Hash of the sources k_density is compiled from: profiles/density_traffic.json is only quoted for these."""
+    h = hashlib.sha256()
+    for f in ("sph_pcisph.hip", "sph_common.h"):
+        h.update(open(os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def dry_run_report(args, np, torch, dist, S, cfg, slab, pos_l, gid_l, N, rank, world, workload_name, backend_name):
+    """--dry-run: what every rank would hand its solver, checked across ranks — the owned sets of the slices partition the
+    particles — and reported as a line without a value. Exercises launcher, rendezvous, cuts, slices, heartbeats."""
+    if os.environ.get("SPHMI_BENCH_TEST_HANG_RANK") == str(rank):  # test hook: this rank goes silent (watchdog test)
+        time.sleep(3600)
+    lay = S.particle_layers(pos_l, cfg)
+    owned = (lay >= slab.layerLo) & (lay < slab.layerHi)
+    stats = torch.tensor([float(owned.sum()), float(gid_l[owned].astype(np.float64).sum()), float(gid_l.size)], dtype=torch.float64)
+    gathered = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(gathered, stats)
+    g = np.stack([t.numpy() for t in gathered])
+    ok = bool(int(g[:, 0].sum()) == N and abs(g[:, 1].sum() - N * (N - 1) / 2.0) < 0.5)
+    if rank == 0:
+        print(json.dumps({"metric": "particle-steps/sec (whole node)", "value": None, "unit": "particle-steps/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "dry_run": True, "dist_backend": backend_name,
+                          "config": {"workload": workload_name, "particles": N},
+                          "halo": {"local_particles_per_rank": g[:, 2].astype(int).tolist(),
+                                   "owned_particles_per_rank": g[:, 0].astype(int).tolist(),
+                                   "owned_sets_partition_all_particles": ok}}), flush=True)
+    beat("done")
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(5)
+
+
+def _timed_steps(solver, torch, first, k):
+    torch.cuda.synchronize()
+    e0 = time.perf_counter()
+    for i in range(k):
+        solver.step(first + i)
+    torch.cuda.synchronize()
+    return time.perf_counter() - e0
+
+
+def _stage_pass(solver, first, k):
+    solver.set_stage_timing(True)
+    solver.reset_stage_times()
+    for i in range(k):
+        solver.step(first + i)
+    st = solver.stage_times()
+    solver.set_stage_timing(False)
+    return {a: round(ms / k, 5) for a, (ms, cnt) in st.items() if cnt}
+
+
+def extra_config2(scenes, sphmi, torch, device, stream):
+    """BASELINE config #2 (1M cube, reference-exact 16-bit cell ids)."""
+    b2, l2, m2 = WORKLOADS["config2_1M_cube"]
+    sc2 = scenes.liquid_box(b2, l2, mask=m2)
+    sc2["cfg"].device = device
+    sc2["cfg"].stream = stream.cuda_stream
+    s2 = sphmi.owHIPSolver(sc2["cfg"], sc2["position"], sc2["velocity"])
+    n2 = sc2["cfg"].particleCount
+    for i in range(5):
+        s2.step(i)
+    k = 50
+    w2 = _timed_steps(s2, torch, 5, k)
+    out = {"particles": n2, "cell_ids": "ref16", "steps": k, "ms_per_step": round(w2 * 1e3 / k, 4),
+           "value": round(n2 * k / w2, 1), "stages_ms": _stage_pass(s2, 55, 20)}
+    s2.close()
+    return out
+
+
+def extra_worm(np, sphmi, torch, device, stream):
+    """BASELINE config #3: the reference's generated worm scene (owHelper.cpp:709-1429; elastic matter, membranes), muscles driven
+    by the signal of main_sim.py after every step (owPhysicsFluidSimulator.cpp:134-141), shipped box, 16-bit cell ids."""
+    cfg = sphmi.default_config()
+    w = sphmi.generate_worm(cfg)
+    cfg.device = device
+    cfg.stream = stream.cuda_stream
+    s = sphmi.owHIPSolver(cfg, w["position"], w["velocity"], w["elastic"], w["membranes"], w["particle_membranes"])
+    n = cfg.particleCount
+
+    def run(first, k):
+        for i in range(first, first + k):
+            s.step(i)
+            s.updateMuscleActivityData(sphmi.muscle_signal(i, cfg.muscleCount))
+    run(0, 5)
+    torch.cuda.synchronize()
+    k = 50
+    e0 = time.perf_counter()
+    run(5, k)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - e0
+    s.set_stage_timing(True)
+    s.reset_stage_times()
+    run(55, 20)
+    st = s.stage_times()
+    s.set_stage_timing(False)
+    pos = s.read_position_buffer()
+    out = {"particles": n, "elastic": w["numOfElasticP"], "liquid": w["numOfLiquidP"], "boundary": w["numOfBoundaryP"],
+           "membranes": int(cfg.numOfMembranes), "muscles": "on", "steps": k, "ms_per_step": round(wall * 1e3 / k, 4),
+           "value": round(n * k / wall, 1), "stages_ms": {a: round(ms / 20, 5) for a, (ms, cnt) in st.items() if cnt},
+           "finite": bool(np.isfinite(pos).all())}
+    s.close()
+    return out
+
+
+def extra_dam_break(np, scenes, sphmi, torch, device, stream, evolve=1500):
+    """A disordered state: a 0.72 M-particle liquid column (1.1 M with the shell) that has been collapsing for `evolve` steps on
+    the GPU — dense cells, long candidate lists, the exact walk of findNeighbors in use (dbg[0..3] per step)."""
+    b, l, m = DAM_BREAK
+    sc = scenes.liquid_box(b, l, mask=m)
+    sc["cfg"].device = device
+    sc["cfg"].stream = stream.cuda_stream
+    s = sphmi.owHIPSolver(sc["cfg"], sc["position"], sc["velocity"])
+    n, nl = sc["cfg"].particleCount, sc["numOfLiquidP"]
+    k = 50
+    rest = _timed_steps(s, torch, 0, k)  # the resting column, for comparison
+    for i in range(k, evolve):
+        s.step(i)
+    wall = _timed_steps(s, torch, evolve, k)
+    s.set_stage_timing(True)
+    s.reset_stage_times()  # (also zeroes the fallback counters)
+    for i in range(20):
+        s.step(evolve + k + i)
+    st = s.stage_times()
+    s.set_stage_timing(False)
+    c = s.buffer("debugCounters")
+    pos = s.read_position_buffer()
+    out = {"particles": n, "liquid": nl, "evolved_steps": evolve, "steps": k, "ms_per_step": round(wall * 1e3 / k, 4),
+           "value": round(n * k / wall, 1), "ms_per_step_at_rest": round(rest * 1e3 / k, 4),
+           "stages_ms": {a: round(ms / 20, 5) for a, (ms, cnt) in st.items() if cnt},
+           "find_neighbors_exact_walks_per_step": {"cell_not_staged": int(c[0]) // 20, "list_overflow": int(c[1]) // 20,
+                                                   "rows_without_16bit_ids": int(c[2]) // 20, "runs_dropped": int(c[3]) // 20},
+           "mean_y_of_liquid_in_h": round(float(pos[:nl, 1].mean() / sc["cfg"].h), 2),
+           "front_x_in_h": round(float(pos[:nl, 0].max() / sc["cfg"].h), 2), "finite": bool(np.isfinite(pos).all())}
+    s.close()
+    return out
 
 
 if __name__ == "__main__":

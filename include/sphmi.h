@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 #define SPHMI_ABI_VERSION 2
+#define SPH_MAX_PARTICLES ((1 << 27) - 1) /* capacity ceiling of one solver: the tiled neighbour map is addressed with 32-bit
+                                             element indices (32 slots x 2^27 particles = 2^32); sph_create rejects more */
 #define SPH_MAX_NEIGHBOR_COUNT 32 /* owOpenCLConstant.h:4 */
 #define SPH_MAX_MEMBRANES_INCLUDING_SAME_PARTICLE 7 /* owOpenCLConstant.h:6 */
 #define SPH_LIQUID_PARTICLE 1   /* owOpenCLConstant.h:8-10 */
@@ -47,7 +49,7 @@ typedef struct sph_config {
   int32_t abi_version;      /* SPHMI_ABI_VERSION */
   int32_t particleCount;    /* PARTICLE_COUNT */
   int32_t capacity;         /* buffers are sized for this many particles (slab decomposition: the count varies per step);
-                               0 = particleCount */
+                               0 = particleCount. At most SPH_MAX_PARTICLES (2^27 - 1 = 134,217,727) */
   int32_t gridCellsX, gridCellsY, gridCellsZ, gridCellCount; /* owOpenCLSolver.cpp:14-17 */
   uint32_t cellIdMask;      /* 0xffff = reference behaviour (sphFluid.cl:229,377); 0xffffffff = wide */
   float h, hashGridCellSize, hashGridCellSizeInv, simulationScale, simulationScaleInv; /* owPhysicsConstant.h:19-24 */
@@ -112,6 +114,20 @@ int sph_read_position(sph_solver* s, float* out4N);
 int sph_read_velocity(sph_solver* s, float* out4N);
 int sph_read_density(sph_solver* s, float* outN);
 int sph_read_particle_index(sph_solver* s, uint32_t* out2N);
+
+/* read_position_buffer without the wait. The reference ends every simulationStep() with a blocking 16N-byte read
+ * (owPhysicsFluidSimulator.cpp:115, owOpenCLSolver.h:60); here the copy can run on a stream of its own under the NEXT step's
+ * search and PCISPH stages: sph_read_position_async returns at once, the positions of the steps enqueued so far land in
+ * out4N in the background, and the next kernel that writes positions (integrate, the last kernel of a step) waits for the
+ * copy on the device. sph_read_position_wait blocks until the last requested copy has landed (and reports a blown-up state
+ * like sph_read_position); a second sph_read_position_async waits for the previous one first. out4N must stay valid until
+ * then. For the copy to overlap, out4N must be DMA-able: memory that is already pinned (hipHostMalloc / hipHostRegister) is
+ * used as it is, any other buffer is page-locked in place with hipHostRegister on first use (kept until sph_destroy or
+ * sph_host_unregister — call that before freeing the buffer); if that fails the copy goes through a pinned staging area and
+ * sph_read_position_wait does the final memcpy. */
+int sph_read_position_async(sph_solver* s, float* out4N);
+int sph_read_position_wait(sph_solver* s);
+int sph_host_unregister(sph_solver* s, void* buffer);
 
 /* Test/inspection export in the reference's layout. Names: position[2N f4] velocity[2N f4]
  * sortedPosition[2N f4] sortedVelocity[N f4] acceleration[2N f4] neighborMap[32N f2] neighborIds[32N i32]
@@ -184,6 +200,9 @@ int sph_slab_read(sph_solver* s, float* position4, float* velocity4, uint32_t* g
 
 const char* sph_last_error(void);
 int sph_abi_version(void);
+/* What the loaded binary was built as: "libsphmi gfx950 abi 2" for the product build; diagnostic (timing-only, INVALID results)
+ * variants add the names of their switches, each containing "DIAG". */
+const char* sph_build_info(void);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,18 @@ int sphmi_generate_box(const sph_config* cfg, double xmax_in_h, double ymax_in_h
                        float spacing, float ox, float oy, float oz, float jitter, uint64_t seed, float* position4N,
                        float* velocity4N);
 
+/* The same box for one rank of a z-slab decomposition (bench.py --gpus N, sphmi/slab.py), without materialising the whole
+ * scene per rank: _layer_histogram counts the particles per z cell layer (layer = (int)(z * hashGridCellSizeInv), as
+ * hashParticles computes it, sphFluid.cl:199) into hist[0..layers), returning SPH_ERR_SIZE if a particle lies outside;
+ * _slice writes only the particles of layers [layerLo, layerHi) — in generation order, i.e. ascending global id — together
+ * with their global ids (index in the full scene). Call it with position == NULL first to get *count. Same particles, bit for
+ * bit, as the corresponding rows of sphmi_generate_box. No reference counterpart (the reference is single-device). */
+int sphmi_box_layer_histogram(const sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, int lx, int ly, int lz,
+                              float spacing, float ox, float oy, float oz, float jitter, uint64_t seed, int64_t* hist, int layers);
+int sphmi_generate_box_slice(const sph_config* cfg, double xmax_in_h, double ymax_in_h, double zmax_in_h, int lx, int ly, int lz,
+                             float spacing, float ox, float oy, float oz, float jitter, uint64_t seed, int layerLo, int layerHi,
+                             float* position4n, float* velocity4n, uint32_t* globalIds, int capacity, int* count);
+
 /* The worm scene owHelper::generateConfiguration builds (owHelper.cpp:104-1429): an elastic worm shell
  * (two radial layers, 199 cross-sections) with its triangulated membrane, springs to every elastic / boundary particle within
  * r0*sqrt(2.7) (rest length 0.95 of the distance; lengthwise springs between "green" shell particles carry one of 96 muscle

@@ -10,6 +10,8 @@
 #include "sph_common.h"
 #include "sph_fastmath.h"
 
+#define SPH_STR_(x) #x
+#define SPH_STR(x) SPH_STR_(x)
 static thread_local char g_err[512] = "";
 void sph_set_error(const char* fmt, ...) {
   va_list ap;
@@ -20,6 +22,31 @@ void sph_set_error(const char* fmt, ...) {
 
 extern "C" const char* sph_last_error(void) { return g_err; }
 extern "C" int sph_abi_version(void) { return SPHMI_ABI_VERSION; }
+
+// What this binary was built as. Diagnostic / timing-only variants (make variant EXTRA=-D...) compute INVALID results; a
+// benchmark must not load one unnoticed (bench.py prints this string and refuses a build whose info contains "DIAG").
+extern "C" const char* sph_build_info(void) {
+  return "libsphmi gfx950 abi " SPH_STR(SPHMI_ABI_VERSION)
+#ifdef DIAG_OWN_GATHER
+         " DIAG_OWN_GATHER(invalid results)"
+#endif
+#ifdef DIAG_NO_WALK
+         " DIAG_NO_WALK(invalid results)"
+#endif
+#ifdef DIAG_NO_REPLAY
+         " DIAG_NO_REPLAY(invalid results)"
+#endif
+#ifdef FN_STAMPS
+         " FN_STAMPS"
+#endif
+#ifdef NO_XCD_REMAP
+         " NO_XCD_REMAP"
+#endif
+#ifdef SPH_VARIANT
+         " variant:" SPH_STR(SPH_VARIANT)
+#endif
+      ;
+}
 
 // stage progress bits for the order contract of simulationStep()
 enum { P_HASH = 1, P_SORT = 2, P_SORTPOST = 4, P_INDEXX = 8, P_INDEXPOST = 16, P_FIND = 32, P_DENSITY = 64, P_FORCES = 128,
@@ -155,7 +182,9 @@ extern "C" int sph_set_stage_timing(sph_solver* s, int enable) {
 extern "C" int sph_reset_stage_times(sph_solver* s) {
   if (!s) return SPH_ERR_INVALID;
   int rc = resolve_pending(s);
-  hipMemsetAsync(s->d.dbg, 0, sizeof(uint32_t) * SPH_DBG_WORDS, s->stream);
+  // (every diagnostic counter except dbg[6], the non-finite-coordinate count that check_finite_state reports)
+  hipMemsetAsync(s->d.dbg, 0, sizeof(uint32_t) * 6, s->stream);
+  hipMemsetAsync(s->d.dbg + 7, 0, sizeof(uint32_t) * (SPH_DBG_WORDS - 7), s->stream);
   memset(s->stageMs, 0, sizeof(s->stageMs));
   memset(s->stageLaunches, 0, sizeof(s->stageLaunches));
   return rc;
@@ -199,6 +228,13 @@ static void free_all(sph_solver* s) {
                   s->blockHist};
   for (void* p : ptrs) if (p) hipFree(p);
   if (s->slabHost) hipHostFree(s->slabHost);
+  for (int i = 0; i < s->numHostRegs; i++) hipHostUnregister(s->hostRegs[i].p);
+  s->numHostRegs = 0;
+  if (s->copyStage) hipHostFree(s->copyStage);
+  if (s->pinnedFlags) hipHostFree(s->pinnedFlags);
+  if (s->evReadReady) hipEventDestroy(s->evReadReady);
+  if (s->evCopyDone) hipEventDestroy(s->evCopyDone);
+  if (s->copyStream) hipStreamDestroy(s->copyStream);
   if (s->slabMsgEvent) hipEventDestroy(s->slabMsgEvent);
   if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
   free(s->pending);
@@ -209,6 +245,7 @@ extern "C" int sph_destroy(sph_solver* s) {
   if (!s) return SPH_OK;
   hipSetDevice(s->cfg.device);
   if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->copyStream) hipStreamSynchronize(s->copyStream);
   for (int i = 0; i < s->numPending; i++) { hipEventDestroy(s->pending[i].a); hipEventDestroy(s->pending[i].b); }
   s->numPending = 0;
   free_all(s);
@@ -223,7 +260,13 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   if (cfg->abi_version != SPHMI_ABI_VERSION) { sph_set_error("sph_config.abi_version %d != %d", cfg->abi_version, SPHMI_ABI_VERSION); return SPH_ERR_INVALID; }
   const int N = cfg->particleCount;
   const int cap = cfg->capacity > 0 ? cfg->capacity : N;
-  if (N <= 0 || cap < N || (long long)cap * 32 >= 0x100000000LL) { sph_set_error("particleCount %d / capacity %d out of range", N, cap); return SPH_ERR_INVALID; }
+  // (k_find_neighbors forms 32-bit element indices into the tiled neighbour map, 32 slots per particle: capacity * 32 < 2^32)
+  static_assert((long long)SPH_MAX_PARTICLES * SPH_MAXN < 0x100000000LL, "uint32 mapBase in k_find_neighbors");
+  if (N <= 0 || cap < N || cap > SPH_MAX_PARTICLES) {
+    sph_set_error("particleCount %d / capacity %d out of range: one solver holds at most %d particles (2^27 - 1; 32-bit neighbour-map "
+                  "indices)", N, cap, SPH_MAX_PARTICLES);
+    return SPH_ERR_INVALID;
+  }
   if (cfg->gridCellsX <= 0 || cfg->gridCellsY <= 0 || cfg->gridCellsZ <= 0 ||
       (long long)cfg->gridCellsX * cfg->gridCellsY * cfg->gridCellsZ != (long long)cfg->gridCellCount) {
     sph_set_error("gridCellCount does not equal gridCellsX*gridCellsY*gridCellsZ");
@@ -623,15 +666,22 @@ static int d2h(sph_solver* s, void* dst, const void* src, size_t bytes) {
   return SPH_OK;
 }
 
-// dbg[6]: particles with a non-finite coordinate seen by the hash kernel since the last check (the state has blown up)
+// dbg[6]: particles with a non-finite coordinate seen by the hash kernel (the state has blown up). Sticky: once seen, every
+// blocking call keeps reporting it until the solver is destroyed — a caller that ignores one SPH_ERR_INVALID does not continue
+// silently on NaN state.
+static int report_blown_up(sph_solver* s) {
+  sph_set_error("%llu particle coordinate(s) were not finite: the simulation state has blown up", (unsigned long long)s->blownUp);
+  return SPH_ERR_INVALID;
+}
 static int check_finite_state(sph_solver* s) {
   uint32_t bad = 0;
   SPH_HIP(hipMemcpyAsync(&bad, s->d.dbg + 6, sizeof(bad), hipMemcpyDeviceToHost, s->stream));
   SPH_HIP(hipStreamSynchronize(s->stream));
-  if (!bad) return SPH_OK;
-  SPH_HIP(hipMemsetAsync(s->d.dbg + 6, 0, sizeof(uint32_t), s->stream));
-  sph_set_error("%u particle coordinate(s) are not finite: the simulation state has blown up", bad);
-  return SPH_ERR_INVALID;
+  if (bad) {
+    s->blownUp += bad;
+    SPH_HIP(hipMemsetAsync(s->d.dbg + 6, 0, sizeof(uint32_t), s->stream));
+  }
+  return s->blownUp ? report_blown_up(s) : SPH_OK;
 }
 
 extern "C" int sph_read_position(sph_solver* s, float* out) {
@@ -639,6 +689,96 @@ extern "C" int sph_read_position(sph_solver* s, float* out) {
   const int rc = d2h(s, out, s->d.posOrig, sizeof(float4) * (size_t)s->d.N);
   return rc != SPH_OK ? rc : check_finite_state(s);
 }
+// ---- asynchronous read_position_buffer. The reference's step always ends with a blocking 16N-byte read
+// (owPhysicsFluidSimulator.cpp:115; 264 MB at 16.5 M particles: +45 % on the step when it is waited for). posOrig is written by
+// exactly one kernel per step, the last one (integrate; + the membrane finalize pass), so the copy of step t can run on its own
+// stream under the search and PCISPH stages of step t+1: copyStream waits for an event recorded on s->stream when the read is
+// requested, and the next kernel that writes posOrig waits for the copy's event (sph_guard_position_write).
+static int copy_setup(sph_solver* s) {
+  if (s->copyStream) return SPH_OK;
+  SPH_HIP(hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking));
+  SPH_HIP(hipEventCreateWithFlags(&s->evReadReady, hipEventDisableTiming));
+  SPH_HIP(hipEventCreateWithFlags(&s->evCopyDone, hipEventDisableTiming));
+  SPH_HIP(hipHostMalloc((void**)&s->pinnedFlags, sizeof(uint32_t) * 4, hipHostMallocDefault));
+  s->pinnedFlags[0] = 0u;
+  return SPH_OK;
+}
+
+// true if the DMA engine can write [p, p + bytes) directly: pinned already, or page-locked in place now
+static bool host_pinned(sph_solver* s, void* p, size_t bytes) {
+  for (int i = 0; i < s->numHostRegs; i++)
+    if ((char*)p >= (char*)s->hostRegs[i].p && (char*)p + bytes <= (char*)s->hostRegs[i].p + s->hostRegs[i].bytes) return true;
+  unsigned int flags = 0;
+  if (hipHostGetFlags(&flags, p) == hipSuccess) return true;  // hipHostMalloc'ed or registered by the caller
+  (void)hipGetLastError();
+  if (s->numHostRegs >= 8) return false;
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  s->hostRegs[s->numHostRegs].p = p; s->hostRegs[s->numHostRegs].bytes = bytes; s->numHostRegs++;
+  return true;
+}
+
+extern "C" int sph_read_position_wait(sph_solver* s) {
+  ENTER(s);
+  if (!s->copyPending) return s->blownUp ? report_blown_up(s) : SPH_OK;
+  SPH_HIP(hipEventSynchronize(s->evCopyDone));
+  s->copyPending = false;
+  if (s->copyViaStage) memcpy(s->copyUserDst, s->copyStage, sizeof(float4) * (size_t)s->d.N);
+  if (s->pinnedFlags[0]) {  // (the device counter keeps counting; it is cleared by the next blocking check)
+    if (!s->blownUp) s->blownUp = s->pinnedFlags[0];
+    return report_blown_up(s);
+  }
+  return s->blownUp ? report_blown_up(s) : SPH_OK;
+}
+
+extern "C" int sph_read_position_async(sph_solver* s, float* out) {
+  ENTER(s); if (!out) return SPH_ERR_INVALID;
+  int rc = copy_setup(s);
+  if (rc != SPH_OK) return rc;
+  if (s->copyPending) {  // the previous read must have landed before its staging area / flags are reused (long done in a step loop)
+    rc = sph_read_position_wait(s);
+    if (rc != SPH_OK) return rc;
+  }
+  const size_t bytes = sizeof(float4) * (size_t)s->d.N;
+  void* dst = out;
+  s->copyViaStage = false;
+  if (!host_pinned(s, out, bytes)) {
+    if (s->copyStageBytes < bytes) {
+      if (s->copyStage) hipHostFree(s->copyStage);
+      s->copyStage = nullptr; s->copyStageBytes = 0;
+      SPH_HIP(hipHostMalloc(&s->copyStage, bytes, hipHostMallocDefault));
+      s->copyStageBytes = bytes;
+    }
+    dst = s->copyStage;
+    s->copyViaStage = true;
+  }
+  s->copyUserDst = out;
+  SPH_HIP(hipEventRecord(s->evReadReady, s->stream));
+  SPH_HIP(hipStreamWaitEvent(s->copyStream, s->evReadReady, 0));
+  SPH_HIP(hipMemcpyAsync(dst, s->d.posOrig, bytes, hipMemcpyDeviceToHost, s->copyStream));
+  SPH_HIP(hipMemcpyAsync(s->pinnedFlags, s->d.dbg + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s->copyStream));
+  SPH_HIP(hipEventRecord(s->evCopyDone, s->copyStream));
+  s->copyPending = true;
+  return SPH_OK;
+}
+
+extern "C" int sph_host_unregister(sph_solver* s, void* p) {
+  ENTER(s);
+  if (s->copyPending) { const int rc = sph_read_position_wait(s); if (rc != SPH_OK && rc != SPH_ERR_INVALID) return rc; }
+  for (int i = 0; i < s->numHostRegs; i++)
+    if (s->hostRegs[i].p == p) {
+      hipHostUnregister(p);
+      s->hostRegs[i] = s->hostRegs[--s->numHostRegs];
+      return SPH_OK;
+    }
+  return SPH_OK;  // not one of ours: nothing to do
+}
+
+int sph_guard_position_write(sph_solver* s) {
+  if (s->copyPending) SPH_HIP(hipStreamWaitEvent(s->stream, s->evCopyDone, 0));
+  return SPH_OK;
+}
+
 extern "C" int sph_read_velocity(sph_solver* s, float* out) {
   ENTER(s); if (!out) return SPH_ERR_INVALID;
   return d2h(s, out, s->d.velOrig, sizeof(float4) * (size_t)s->d.N);

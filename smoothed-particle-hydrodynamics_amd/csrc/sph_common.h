@@ -102,7 +102,22 @@ struct sph_solver {
   int64_t stageLaunches[SPH_ST_COUNT];
   // host staging for exports
   void* hostScratch; size_t hostScratchBytes;
+  // asynchronous position read-back (sph_read_position_async): a copy stream of its own, ordered against s->stream by events
+  hipStream_t copyStream;
+  hipEvent_t evReadReady, evCopyDone;  // positions final on s->stream / copy landed on the host
+  bool copyPending;                    // a copy was issued and sph_read_position_wait has not run since
+  float* copyUserDst;                  // where the caller wants the data
+  void* copyStage; size_t copyStageBytes;  // pinned staging, only for destinations that cannot be page-locked in place
+  bool copyViaStage;
+  struct HostReg { void* p; size_t bytes; };
+  HostReg hostRegs[8]; int numHostRegs;    // caller buffers page-locked in place by hipHostRegister (released by sph_destroy)
+  uint32_t* pinnedFlags;               // pinned: [0] copy of dbg[6] taken with the last asynchronous read-back
+  uint64_t blownUp;                    // sticky: non-finite coordinates seen so far (check_finite_state)
 };
+
+// Called by every launcher whose kernel WRITES posOrig (integrate, membranes finalize, slab rebuild): makes s->stream wait for
+// an asynchronous position read-back that is still in flight.
+int sph_guard_position_write(sph_solver* s);
 
 void sph_set_error(const char* fmt, ...);
 

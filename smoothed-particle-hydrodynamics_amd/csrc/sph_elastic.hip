@@ -192,6 +192,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_membranes_finalize(SphDev d) {
 
 int sphk_membranes_finalize(sph_solver* s) {
   if (!s->d.hasElastic) return SPH_OK;  // already folded into integrate (`+ 0.f`)
+  { const int g = sph_guard_position_write(s); if (g != SPH_OK) return g; }
   hipLaunchKernelGGL(k_membranes_finalize, dim3(sph_blocks(s->d.N)), dim3(SPH_BLOCK), 0, s->stream, s->d);
   SPH_HIP(hipGetLastError());
   return SPH_OK;

@@ -127,7 +127,9 @@ __device__ __forceinline__ int fn_popc(uint32_t v) { return __popc(v); }
 __device__ __forceinline__ int fn_popc(unsigned long long v) { return __popcll(v); }
 
 // d.dbg layout: [0] particles handed to the exact wave-per-particle walk because a cell was not staged, [1] because a list
-// overflowed, [2] rows without a 16-bit copy because an offset was out of range, [3] candidate runs dropped for LDS capacity. With FN_STAMPS (diagnostic build only): [16..25] cycles / 64 per phase.
+// overflowed, [2] rows without a 16-bit copy because an offset was out of range, [3] candidate runs dropped for LDS capacity;
+// [6] non-finite coordinates seen by the hash kernel (sph_api.hip: check_finite_state; not cleared by sph_reset_stage_times);
+// [8] (wave, batch) pairs of k_pressure_force that left the short division / square-root path (sph_pcisph.hip). With FN_STAMPS (diagnostic build only): [16..25] cycles / 64 per phase.
 #ifdef FN_STAMPS
 #define FN_STAMP(ph)                                                                                      \
   {                                                                                                       \

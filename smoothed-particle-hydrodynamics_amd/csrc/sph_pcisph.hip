@@ -469,6 +469,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_integrate(SphDev d, int nblocks) 
 
 int sphk_integrate(sph_solver* s) {
   const int nb = sph_blocks(s->d.N);
+  { const int g = sph_guard_position_write(s); if (g != SPH_OK) return g; }
   hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, nb);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
@@ -562,6 +563,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
     // simply computed again with the compiler's sqrtf and `/` (same results for the lanes that were inside).
     const float bx = rx, by = ry, bz = rz;
     if (!pf_batch<true>(d, xi, pi_, hq, xj, rpj, jj, rx, ry, rz, ownOk)) {
+      if ((threadIdx.x & 63) == 0) atomicAdd(&d.dbg[8], 1u);  // (wave, batch) pairs recomputed with sqrtf and `/`: rare (tests assert it)
       rx = bx; ry = by; rz = bz;
       pf_batch<false>(d, xi, pi_, hq, xj, rpj, jj, rx, ry, rz, true);
     }
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
 
 static int launch_pressure_force(sph_solver* s, int fuse, const SphDev& d) {
   const int nb = sph_blocks(s->d.N);
+  if (fuse == 2) { const int g = sph_guard_position_write(s); if (g != SPH_OK) return g; }  // (+ integrate: writes posOrig)
   if (fuse == 0) hipLaunchKernelGGL((k_pressure_force<0>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   else if (fuse == 1) hipLaunchKernelGGL((k_pressure_force<1>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);
   else hipLaunchKernelGGL((k_pressure_force<2>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, d, nb);

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_msg(SphDev d, sph_slab
 
 int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept) {
   const int total = kept + nDown + nUp;
+  { const int g = sph_guard_position_write(s); if (g != SPH_OK) return g; }
   if (kept) hipLaunchKernelGGL(k_slab_merge_kept, dim3(sph_blocks(kept)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvDown, nDown, recvUp, nUp);
   if (nDown) hipLaunchKernelGGL(k_slab_merge_msg, dim3(sph_blocks(nDown)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvDown, nDown, recvUp, nUp, s->slabCounts + 3);
   if (nUp) hipLaunchKernelGGL(k_slab_merge_msg, dim3(sph_blocks(nUp)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvUp, nUp, recvDown, nDown, s->slabCounts + 3);
@@ -226,6 +227,8 @@ int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const 
 int sphk_slab_sort_rebuild(sph_solver* s, int total) {
   hipLaunchKernelGGL(k_iota, dim3(sph_blocks(total)), dim3(SPH_BLOCK), 0, s->stream, s->d.vals, total);
   int rc = sphk_sort_pairs(s, total, s->slab.globalIdBits);  // stable LSD radix sort by global id (keys), vals follow
+  if (rc != SPH_OK) return rc;
+  rc = sph_guard_position_write(s);
   if (rc != SPH_OK) return rc;
   hipLaunchKernelGGL(k_slab_gather, dim3(sph_blocks(total)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, total);
   SPH_HIP(hipGetLastError());

@@ -69,8 +69,14 @@ static CompactKey compact_plan(const sph_solver* s, int* bits) {
 // when the compacted keys take fewer radix passes than the real ones.
 int sphk_step_sort_bits(const sph_solver* s, bool* compact) {
   int bits = s->sortBits;
-  compact_plan(s, &bits);
-  *compact = s->d.cellMask == 0xffffffffu && sph_sort_passes(bits) < sph_sort_passes(s->sortBits);
+  const CompactKey c = compact_plan(s, &bits);
+  // The compacted key is monotone in the real cell id only while k_hash_compact's clamps never bite: every coordinate a particle
+  // of the box can have must hash to cx, cy, cz inside [0, used). A box that starts below zero (negative coordinates truncate
+  // towards zero and alias in the real ids) or whose `used` was capped by the declared grid keeps the real keys.
+  const SphDev& d = s->d;
+  const bool clampFree = d.xmin >= 0.f && d.ymin >= 0.f && d.zmin >= 0.f && (int)(d.xmax * d.cellSizeInv) < c.usedX &&
+                         (int)(d.ymax * d.cellSizeInv) < c.usedY && (s->hasSlab || (int)(d.zmax * d.cellSizeInv) < c.czBase + c.layers);
+  *compact = clampFree && s->d.cellMask == 0xffffffffu && sph_sort_passes(bits) < sph_sort_passes(s->sortBits);
   return *compact ? bits : s->sortBits;
 }
 

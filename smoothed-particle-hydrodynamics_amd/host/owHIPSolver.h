@@ -53,6 +53,12 @@ class owHIPSolver {
   }
   // owOpenCLSolver.h:60-62 — copy failures throw std::runtime_error there (owOpenCLSolver.cpp:727-736)
   void read_position_buffer(float* position_cpp) { check(sph_read_position(s_, position_cpp), "read_position_buffer"); }
+  // The same read without the wait (sph_read_position_async): the 16N-byte copy runs on its own stream under the NEXT step's
+  // kernels and position_cpp is complete after wait_position_buffer() — call that where the data is consumed (the reference:
+  // owPhysicsFluidSimulator::getPosition_cpp(), which the viewer calls once per frame). position_cpp is page-locked in place on
+  // first use. INTEGRATION.md §1 shows the two lines.
+  void read_position_buffer_async(float* position_cpp) { check(sph_read_position_async(s_, position_cpp), "read_position_buffer_async"); }
+  void wait_position_buffer() { check(sph_read_position_wait(s_), "wait_position_buffer"); }
   void read_density_buffer(float* density_cpp) { check(sph_read_density(s_, density_cpp), "read_density_buffer"); }
   void read_particleIndex_buffer(unsigned int* particleIndexBuffer) {
     check(sph_read_particle_index(s_, particleIndexBuffer), "read_particleIndex_buffer");

@@ -105,6 +105,64 @@ inline void put(float* a, size_t i, float x, float y, float z, float w) {
   a[4 * i + 0] = x; a[4 * i + 1] = y; a[4 * i + 2] = z; a[4 * i + 3] = w;
 }
 
+// Visits every particle of the synthetic box in generation order (liquid lattice, x fastest; then the boundary shell in the
+// visiting order and float expressions of owHelper.cpp:776-927): emit(index, x, y, z, type, vx, vy, vz, vw).
+template <typename Emit>
+size_t walk_box(const sph_config* cfg, double xm, double ym, double zm, int lx, int ly, int lz, float spacing, float ox,
+                       float oy, float oz, float jitter, uint64_t seed, Emit emit) {
+  size_t i = 0;
+  Pcg32 rng(seed);
+  // liquid lattice (type 1.1 as in configuration/position*.txt), x fastest
+  for (int iz = 0; iz < lz; iz++)
+    for (int iy = 0; iy < ly; iy++)
+      for (int ix = 0; ix < lx; ix++) {
+        float x = ox + (float)ix * spacing, y = oy + (float)iy * spacing, z = oz + (float)iz * spacing;
+        if (jitter > 0.f) { x += jitter * rng.uniform_pm1(); y += jitter * rng.uniform_pm1(); z += jitter * rng.uniform_pm1(); }
+        emit(i, x, y, z, 1.1f, 0.f, 0.f, 0.f, 0.f);
+        i++;
+      }
+  // boundary shell — owHelper.cpp:776-927 (same visiting order, same float expressions)
+  const BoundaryDims d = boundary_dims(cfg, xm, ym, zm);
+  const int nx = d.nx, ny = d.ny, nz = d.nz;
+  const float r0 = cfg->r0, t = (float)SPH_BOUNDARY_PARTICLE;
+  const float s3 = sqrtf(3.f), s2 = sqrtf(2.f);
+  for (int ix = 0; ix < nx; ix++)
+    for (int iy = 0; iy < ny; iy++) {  // 1 - top and bottom
+      const bool ex = (ix == 0) || (ix == nx - 1), ey = (iy == 0) || (iy == ny - 1);
+      const float px = ix * r0 + r0 / 2, py = iy * r0 + r0 / 2;
+      const float z0 = 0 * r0 + r0 / 2, z1 = (nz - 1) * r0 + r0 / 2;
+      const float sx = 1.f * (ix == 0) - 1 * (ix == nx - 1), sy = 1.f * (iy == 0) - 1 * (iy == ny - 1);
+      if (ex || ey) {
+        const float q = (ex && ey) ? s3 : s2;  // corners / edges
+        emit(i, px, py, z0, t, sx / q, sy / q, 1.f / q, t); i++;
+        emit(i, px, py, z1, t, sx / q, sy / q, -1.f / q, t); i++;
+      } else {  // planes
+        emit(i, px, py, z0, t, 0.f, 0.f, 1.f, t); i++;
+        emit(i, px, py, z1, t, 0.f, 0.f, -1.f, t); i++;
+      }
+    }
+  for (int ix = 0; ix < nx; ix++)
+    for (int iz = 1; iz < nz - 1; iz++) {  // 2 - side walls OX-OZ and opposite
+      const float px = ix * r0 + r0 / 2, pz = iz * r0 + r0 / 2;
+      const float y0 = 0 * r0 + r0 / 2, y1 = (ny - 1) * r0 + r0 / 2;
+      if ((ix == 0) || (ix == nx - 1)) {  // edges; the z component is 0 there because 1 <= iz <= nz-2 (:866,:875)
+        const float nzc = 1.f * ((iz == 0) - (iz == nz - 1)) / s2;
+        emit(i, px, y0, pz, t, 0.f, 1.f / s2, nzc, t); i++;
+        emit(i, px, y1, pz, t, 0.f, -1.f / s2, nzc, t); i++;
+      } else {
+        emit(i, px, y0, pz, t, 0.f, 1.f, 0.f, t); i++;
+        emit(i, px, y1, pz, t, 0.f, -1.f, 0.f, t); i++;
+      }
+    }
+  for (int iy = 1; iy < ny - 1; iy++)
+    for (int iz = 1; iz < nz - 1; iz++) {  // 3 - side walls OY-OZ and opposite
+      const float py = iy * r0 + r0 / 2, pz = iz * r0 + r0 / 2;
+      emit(i, 0 * r0 + r0 / 2, py, pz, t, 1.f, 0.f, 0.f, t); i++;
+      emit(i, (nx - 1) * r0 + r0 / 2, py, pz, t, -1.f, 0.f, 0.f, t); i++;
+    }
+  return i;
+}
+
 }  // namespace
 
 extern "C" {
@@ -222,58 +280,53 @@ int sphmi_generate_box(const sph_config* cfg, double xm, double ym, double zm, i
   int nl = 0, nb = 0;
   int rc = sphmi_box_counts(cfg, xm, ym, zm, lx, ly, lz, &nl, &nb);
   if (rc != SPH_OK || !position || !velocity) return rc != SPH_OK ? rc : SPH_ERR_INVALID;
-  size_t i = 0;
-  Pcg32 rng(seed);
-  // liquid lattice (type 1.1 as in configuration/position*.txt), x fastest
-  for (int iz = 0; iz < lz; iz++)
-    for (int iy = 0; iy < ly; iy++)
-      for (int ix = 0; ix < lx; ix++) {
-        float x = ox + (float)ix * spacing, y = oy + (float)iy * spacing, z = oz + (float)iz * spacing;
-        if (jitter > 0.f) { x += jitter * rng.uniform_pm1(); y += jitter * rng.uniform_pm1(); z += jitter * rng.uniform_pm1(); }
-        put(position, i, x, y, z, 1.1f);
-        put(velocity, i, 0.f, 0.f, 0.f, 0.f);
-        i++;
-      }
-  // boundary shell — owHelper.cpp:776-927 (same visiting order, same float expressions)
-  const BoundaryDims d = boundary_dims(cfg, xm, ym, zm);
-  const int nx = d.nx, ny = d.ny, nz = d.nz;
-  const float r0 = cfg->r0, t = (float)SPH_BOUNDARY_PARTICLE;
-  const float s3 = sqrtf(3.f), s2 = sqrtf(2.f);
-  for (int ix = 0; ix < nx; ix++)
-    for (int iy = 0; iy < ny; iy++) {  // 1 - top and bottom
-      const bool ex = (ix == 0) || (ix == nx - 1), ey = (iy == 0) || (iy == ny - 1);
-      const float px = ix * r0 + r0 / 2, py = iy * r0 + r0 / 2;
-      const float z0 = 0 * r0 + r0 / 2, z1 = (nz - 1) * r0 + r0 / 2;
-      const float sx = 1.f * (ix == 0) - 1 * (ix == nx - 1), sy = 1.f * (iy == 0) - 1 * (iy == ny - 1);
-      if (ex || ey) {
-        const float q = (ex && ey) ? s3 : s2;  // corners / edges
-        put(position, i, px, py, z0, t); put(velocity, i, sx / q, sy / q, 1.f / q, t); i++;
-        put(position, i, px, py, z1, t); put(velocity, i, sx / q, sy / q, -1.f / q, t); i++;
-      } else {  // planes
-        put(position, i, px, py, z0, t); put(velocity, i, 0, 0, 1, t); i++;
-        put(position, i, px, py, z1, t); put(velocity, i, 0, 0, -1, t); i++;
-      }
-    }
-  for (int ix = 0; ix < nx; ix++)
-    for (int iz = 1; iz < nz - 1; iz++) {  // 2 - side walls OX-OZ and opposite
-      const float px = ix * r0 + r0 / 2, pz = iz * r0 + r0 / 2;
-      const float y0 = 0 * r0 + r0 / 2, y1 = (ny - 1) * r0 + r0 / 2;
-      if ((ix == 0) || (ix == nx - 1)) {  // edges; the z component is 0 there because 1 <= iz <= nz-2 (:866,:875)
-        const float nzc = 1.f * ((iz == 0) - (iz == nz - 1)) / s2;
-        put(position, i, px, y0, pz, t); put(velocity, i, 0, 1.f / s2, nzc, t); i++;
-        put(position, i, px, y1, pz, t); put(velocity, i, 0, -1.f / s2, nzc, t); i++;
-      } else {
-        put(position, i, px, y0, pz, t); put(velocity, i, 0, 1, 0, t); i++;
-        put(position, i, px, y1, pz, t); put(velocity, i, 0, -1, 0, t); i++;
-      }
-    }
-  for (int iy = 1; iy < ny - 1; iy++)
-    for (int iz = 1; iz < nz - 1; iz++) {  // 3 - side walls OY-OZ and opposite
-      const float py = iy * r0 + r0 / 2, pz = iz * r0 + r0 / 2;
-      put(position, i, 0 * r0 + r0 / 2, py, pz, t); put(velocity, i, 1, 0, 0, t); i++;
-      put(position, i, (nx - 1) * r0 + r0 / 2, py, pz, t); put(velocity, i, -1, 0, 0, t); i++;
-    }
-  return (i == (size_t)nl + (size_t)nb) ? SPH_OK : SPH_ERR_SIZE;
+  const size_t n = walk_box(cfg, xm, ym, zm, lx, ly, lz, spacing, ox, oy, oz, jitter, seed,
+                            [&](size_t i, float x, float y, float z, float w, float vx, float vy, float vz, float vw) {
+                              put(position, i, x, y, z, w);
+                              put(velocity, i, vx, vy, vz, vw);
+                            });
+  return (n == (size_t)nl + (size_t)nb) ? SPH_OK : SPH_ERR_SIZE;
+}
+
+// z cell layer of a particle exactly as hashParticles computes it (sphFluid.cl:199): (int)(z * hashGridCellSizeInv) in float
+static inline int box_layer(const sph_config* cfg, float z) { return (int)(z * cfg->hashGridCellSizeInv); }
+
+int sphmi_box_layer_histogram(const sph_config* cfg, double xm, double ym, double zm, int lx, int ly, int lz, float spacing,
+                              float ox, float oy, float oz, float jitter, uint64_t seed, int64_t* hist, int layers) {
+  int nl = 0, nb = 0;
+  int rc = sphmi_box_counts(cfg, xm, ym, zm, lx, ly, lz, &nl, &nb);
+  if (rc != SPH_OK || !hist || layers <= 0) return rc != SPH_OK ? rc : SPH_ERR_INVALID;
+  for (int i = 0; i < layers; i++) hist[i] = 0;
+  bool outside = false;
+  walk_box(cfg, xm, ym, zm, lx, ly, lz, spacing, ox, oy, oz, jitter, seed,
+           [&](size_t, float, float, float z, float, float, float, float, float) {
+             const int l = box_layer(cfg, z);
+             if (l < 0 || l >= layers) outside = true; else hist[l]++;
+           });
+  return outside ? SPH_ERR_SIZE : SPH_OK;
+}
+
+int sphmi_generate_box_slice(const sph_config* cfg, double xm, double ym, double zm, int lx, int ly, int lz, float spacing,
+                             float ox, float oy, float oz, float jitter, uint64_t seed, int layerLo, int layerHi,
+                             float* position, float* velocity, uint32_t* globalIds, int capacity, int* count) {
+  int nl = 0, nb = 0;
+  int rc = sphmi_box_counts(cfg, xm, ym, zm, lx, ly, lz, &nl, &nb);
+  if (rc != SPH_OK || !count) return rc != SPH_OK ? rc : SPH_ERR_INVALID;
+  const bool fill = position && velocity && globalIds;
+  size_t k = 0;
+  walk_box(cfg, xm, ym, zm, lx, ly, lz, spacing, ox, oy, oz, jitter, seed,
+           [&](size_t i, float x, float y, float z, float w, float vx, float vy, float vz, float vw) {
+             const int l = box_layer(cfg, z);
+             if (l < layerLo || l >= layerHi) return;
+             if (fill && k < (size_t)capacity) {
+               put(position, k, x, y, z, w);
+               put(velocity, k, vx, vy, vz, vw);
+               globalIds[k] = (uint32_t)i;
+             }
+             k++;
+           });
+  *count = (int)k;
+  return (fill && k > (size_t)capacity) ? SPH_ERR_SIZE : SPH_OK;
 }
 
 int sphmi_save_configuration(const char* dir, const float* position, int count, int numOfElasticP, int numOfLiquidP,

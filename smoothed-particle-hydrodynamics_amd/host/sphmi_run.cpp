@@ -2,7 +2,7 @@
 // configuration/position.txt + velocity.txt style files (or generates a synthetic box), constructs the solver through
 // the owOpenCLSolver-compatible facade, and issues the reference's stage sequence with its per-stage timing printout.
 //
-//   sphmi_run --position P.txt --velocity V.txt [--steps N] [--staged] [--out positions.bin] [--quiet]
+//   sphmi_run --position P.txt --velocity V.txt [--steps N] [--staged] [--out positions.bin] [--quiet] [--blocking-readback]
 //   sphmi_run --box 50 50 50 --lattice 100 100 100 [--wide] ...
 //   sphmi_run --worm [--muscles] ...      the generated worm scene of the reference's default start-up (owHelper.cpp:709)
 #include <chrono>
@@ -30,7 +30,7 @@ struct Watch {  // owHelper::refreshTime / watch_report (owHelper.cpp:44-57,1806
 
 int main(int argc, char** argv) {
   const char *posFile = nullptr, *velFile = nullptr, *outFile = nullptr;
-  int steps = 10; bool staged = false, wide = false, quiet = false, muscles = false, worm = false;
+  int steps = 10; bool staged = false, wide = false, quiet = false, muscles = false, worm = false, blockingRead = false;
   double box[3] = {0, 0, 0}; int lat[3] = {0, 0, 0};
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--position") && i + 1 < argc) posFile = argv[++i];
@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--quiet")) quiet = true;
     else if (!strcmp(argv[i], "--muscles")) muscles = true;
     else if (!strcmp(argv[i], "--worm")) worm = true;
+    else if (!strcmp(argv[i], "--blocking-readback")) blockingRead = true;  // the reference's blocking read_position_buffer
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
@@ -124,13 +125,23 @@ int main(int argc, char** argv) {
         ocl_solver->step(iterationCount);
         sph_synchronize(ocl_solver->handle()); helper.report("sph_step (fused): \t%9.3f ms\n");
       }
-      ocl_solver->read_position_buffer(position_cpp.data());  helper.report("_readBuffer: \t\t%9.3f ms\n");
+      // owPhysicsFluidSimulator.cpp:115. Default: the copy is only started here and overlaps the next step (the positions are
+      // consumed after the loop); --blocking-readback waits for it like the reference does.
+      if (blockingRead) ocl_solver->read_position_buffer(position_cpp.data());
+      else ocl_solver->read_position_buffer_async(position_cpp.data());
+      helper.report("_readBuffer: \t\t%9.3f ms\n");
       if (!quiet) printf("------------------------------------\n_Total_step_time:\t%9.3f ms\n------------------------------------\n", helper.elapsed());
       total += helper.elapsed();
       if (muscles) {  // signals computed after step t drive step t+1 (owPhysicsFluidSimulator.cpp:134-141)
         sphmi_muscle_signal(iterationCount, muscle_activation_signal_cpp.data(), cfg.muscleCount);
         ocl_solver->updateMuscleActivityData(muscle_activation_signal_cpp.data());
       }
+    }
+    {
+      helper.refresh();
+      ocl_solver->wait_position_buffer();  // the last step's copy
+      helper.report("");
+      total += helper.elapsed();
     }
     printf("%d steps, %.3f ms/step incl. the 16N-byte position read-back, %.3e particle-steps/s\n", steps, total / steps,
            cfg.particleCount * 1000.0 / (total / steps));

@@ -67,6 +67,10 @@ def host_lib():
                                        C.POINTER(C.c_int)]
         L.sphmi_generate_box.argtypes = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
+        _box = [C.POINTER(SphConfig), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                C.c_float, C.c_float, C.c_float, C.c_uint64]
+        L.sphmi_box_layer_histogram.argtypes = _box + [C.c_void_p, C.c_int]
+        L.sphmi_generate_box_slice.argtypes = _box + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.sphmi_muscle_signal.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.sphmi_trajectory_info.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4
         L.sphmi_trajectory_frame.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
@@ -89,12 +93,13 @@ _STAGE_FUNCS = ["sph_run_clear_buffers", "sph_run_hash_particles", "sph_run_sort
                 "sph_run_compute_interaction_with_membranes", "sph_run_compute_interaction_with_membranes_finalize"]
 EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sph_step", "sph_update_muscles",
                     "sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index",
+                    "sph_read_position_async", "sph_read_position_wait", "sph_host_unregister", "sph_build_info",
                     "sph_read_buffer", "sph_read_neighbor_rows", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
                     "sph_reset_stage_times", "sph_step_sort_passes", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed", "sph_slab_step_begin", "sph_slab_step_messages",
                     "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
-                         "sphmi_generate_box", "sphmi_muscle_signal", "sphmi_save_configuration", "sphmi_worm_counts",
+                         "sphmi_generate_box", "sphmi_box_layer_histogram", "sphmi_generate_box_slice", "sphmi_muscle_signal", "sphmi_save_configuration", "sphmi_worm_counts",
                          "sphmi_generate_worm", "sphmi_trajectory_info", "sphmi_trajectory_frame", "sphmi_trajectory_connections",
                          "sphmi_trajectory_membranes"]
 
@@ -145,8 +150,11 @@ def device_lib():
         L.sph_run_pcisph_integrate.argtypes = [C.c_void_p, C.c_int]
         L.sph_step.argtypes = [C.c_void_p, C.c_int]
         L.sph_update_muscles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        for f in ["sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index"]:
+        for f in ["sph_read_position", "sph_read_velocity", "sph_read_density", "sph_read_particle_index", "sph_read_position_async",
+                  "sph_host_unregister"]:
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.sph_read_position_wait.argtypes = [C.c_void_p]
+        L.sph_build_info.restype = C.c_char_p
         L.sph_read_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.sph_read_neighbor_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.sph_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
@@ -225,6 +233,51 @@ def generate_box(cfg, lx, ly, lz, spacing=None, origin=None, jitter=0.0, seed=20
         raise SphError("sphmi_generate_box failed: %d" % rc)
     cfg.particleCount = n
     return pos, vel, dict(numOfLiquidP=nl.value, numOfElasticP=0, numOfBoundaryP=nb.value)
+
+
+def _box_args(cfg, lx, ly, lz, spacing, origin, jitter, seed):
+    bx = cfg._box_in_h
+    r0 = np.float32(cfg.r0)
+    if spacing is None:
+        spacing = np.float32(0.93) * r0
+    if origin is None:
+        origin = (np.float32(3) * r0,) * 3
+    return [C.byref(cfg), bx[0], bx[1], bx[2], lx, ly, lz, spacing, origin[0], origin[1], origin[2], jitter, seed]
+
+
+def box_counts(cfg, lx, ly, lz):
+    """(numOfLiquidP, numOfBoundaryP) of generate_box without generating anything."""
+    nl, nb = C.c_int(), C.c_int()
+    bx = cfg._box_in_h
+    rc = host_lib().sphmi_box_counts(C.byref(cfg), bx[0], bx[1], bx[2], lx, ly, lz, C.byref(nl), C.byref(nb))
+    if rc:
+        raise SphError("sphmi_box_counts failed: %d" % rc)
+    return nl.value, nb.value
+
+
+def box_layer_histogram(cfg, lx, ly, lz, spacing=None, origin=None, jitter=0.0, seed=20261004):
+    """Particles of generate_box's scene per z cell layer (int64[gridCellsZ]) — what balanced_cuts_hist needs — without
+    materialising the scene."""
+    hist = np.zeros(cfg.gridCellsZ, np.int64)
+    rc = host_lib().sphmi_box_layer_histogram(*_box_args(cfg, lx, ly, lz, spacing, origin, jitter, seed), hist.ctypes.data, hist.size)
+    if rc:
+        raise SphError("sphmi_box_layer_histogram failed: %d" % rc)
+    return hist
+
+
+def generate_box_slice(cfg, lx, ly, lz, layer_lo, layer_hi, spacing=None, origin=None, jitter=0.0, seed=20261004):
+    """The rows of generate_box's scene whose z cell layer lies in [layer_lo, layer_hi), with their global ids (ascending):
+    (position, velocity, global_ids). Does not touch cfg.particleCount."""
+    args = _box_args(cfg, lx, ly, lz, spacing, origin, jitter, seed) + [int(max(layer_lo, -(1 << 30))), int(min(layer_hi, 1 << 30))]
+    n = C.c_int()
+    rc = host_lib().sphmi_generate_box_slice(*args, None, None, None, 0, C.byref(n))
+    if rc:
+        raise SphError("sphmi_generate_box_slice failed: %d" % rc)
+    pos, vel, gid = np.empty((n.value, 4), np.float32), np.empty((n.value, 4), np.float32), np.empty(n.value, np.uint32)
+    rc = host_lib().sphmi_generate_box_slice(*args, pos.ctypes.data, vel.ctypes.data, gid.ctypes.data, n.value, C.byref(n))
+    if rc:
+        raise SphError("sphmi_generate_box_slice failed: %d" % rc)
+    return pos, vel, gid
 
 
 def generate_worm(cfg):
@@ -308,6 +361,11 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def build_info():
+    """sph_build_info() of the loaded libsphmi.so ("DIAG" in it: a timing-only variant with invalid results)."""
+    return device_lib().sph_build_info().decode()
+
+
 class owHIPSolver:
     """Counterpart of owOpenCLSolver (src/owOpenCLSolver.h:28-62): same methods, backed by libsphmi.so."""
 
@@ -371,6 +429,18 @@ class owHIPSolver:
         out = np.empty((self.N, 4), np.float32) if out is None else out
         self._chk(self._L.sph_read_position(self._h, _ptr(out)))
         return out
+
+    def read_position_buffer_async(self, out):
+        """read_position_buffer without the wait (sph_read_position_async): the copy runs under the next step; `out` (C-contiguous
+        float32, 4N) is valid after wait_position_buffer(). The array is page-locked in place on first use and kept alive here."""
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags.c_contiguous and out.size == 4 * self.N):
+            raise SphError("read_position_buffer_async needs a C-contiguous float32 array of 4*N elements")
+        self._async_out = out
+        self._chk(self._L.sph_read_position_async(self._h, _ptr(out)))
+        return out
+
+    def wait_position_buffer(self):
+        return self._chk(self._L.sph_read_position_wait(self._h))
 
     def read_velocity_buffer(self, out=None):
         out = np.empty((self.N, 4), np.float32) if out is None else out
@@ -478,7 +548,7 @@ class owPhysicsFluidSimulator:
         self.muscles = muscles
         self.position_cpp = np.array(position_cpp, np.float32).reshape(-1, 4)
 
-    def simulationStep(self, read_back=True):
+    def simulationStep(self, read_back=True, async_read_back=False):
         s = self.ocl_solver
         if self.fused:
             s.step(self.iterationCount)
@@ -497,12 +567,17 @@ class owPhysicsFluidSimulator:
             s._run_pcisph_integrate(self.iterationCount)
             s._run_clearMembraneBuffers(); s._run_computeInteractionWithMembranes()
             s._run_computeInteractionWithMembranes_finalize()
-        if read_back:
+        if read_back and async_read_back:  # the copy overlaps the next step; getPosition_cpp() waits for it
+            s.read_position_buffer_async(self.position_cpp)
+        elif read_back:
             s.read_position_buffer(self.position_cpp)
         if self.muscles:  # signals computed after step t drive step t+1 (owPhysicsFluidSimulator.cpp:134-141)
             s.updateMuscleActivityData(muscle_signal(self.iterationCount, self.cfg.muscleCount))
         self.iterationCount += 1
 
-    def getPosition_cpp(self): return self.position_cpp
+    def getPosition_cpp(self):
+        self.ocl_solver.wait_position_buffer()  # (no-op unless simulationStep(async_read_back=True) left a copy in flight)
+        return self.position_cpp
+
     def getDensity_cpp(self): return self.ocl_solver.read_density_buffer()
     def getParticleIndex_cpp(self): return self.ocl_solver.read_particleIndex_buffer()

@@ -20,6 +20,13 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def liquid_box_config(box_in_h, mask=0xffff):
+    """The sph_config of liquid_box's scene without any particles (particleCount is left 0)."""
+    cfg = sphmi.default_config()
+    sphmi.set_box(cfg, box_in_h[0], box_in_h[1], box_in_h[2], mask)
+    return cfg
+
+
 def liquid_box(box_in_h, lattice, spacing_in_r0=0.93, jitter_in_r0=0.0, mask=0xffff, origin_in_r0=(3.0, 3.0, 3.0),
                seed=20261004):
     """Pure-liquid synthetic box: liquid lattice first, then the reference boundary shell."""

@@ -687,3 +687,165 @@ def test_bench_line_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "traffic" in rf and rf["bytes_per_launch"] == d["config"]["particles"] * 132
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "particle-steps/s"
+
+
+# ---------------------------------------------------------------------------------------------- round 3
+def _pressure_force_fallbacks(hip):
+    """(wave, batch) pairs of k_pressure_force recomputed with sqrtf and `/` since the last reset_stage_times (dbg[8])."""
+    return int(hip.buffer("debugCounters")[8])
+
+
+def test_pressure_active_wide_million_particles_every_buffer():
+    """Pressure-ACTIVE state at scale (the lattices at 0.93 r0 keep p = 0 for ~70 steps): 1.33 M liquid particles at 0.85 r0 — the
+    `tiny_compressed` recipe — in a wide-mode box of 152,561 declared cells, three fused steps, EVERY buffer against the oracle.
+    pcisph_correctPressure and the value / division arithmetic of pcisph_computePressureForceAcceleration
+    (sphFluid.cl:1062-1098, 1160-1180) see non-zero pressures from the first iteration on, and they go through the short division /
+    square-root sequences of sph_fastmath.h: the fallback counter must stay (almost) idle."""
+    sc = scenes.liquid_box((60.0, 40.0, 60.0), (125, 85, 125), spacing_in_r0=0.85, mask=0xffffffff)
+    cfg = sc["cfg"]
+    N = cfg.particleCount
+    assert N > 1300000 and cfg.gridCellCount > 65536
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16)
+    hip.reset_stage_times()
+    for it in range(3):
+        hip.step(it)
+        ora.step()
+        got, want = canon_hip(hip, N), canon_ora(ora, N)
+        assert want["pressure"].max() > 0, "step %d: the scene must be pressure-active" % it
+        assert_same(got, want, "compressed wide 1.3M, step %d" % it, FUSED_SKIP)
+    assert (want["pressure"] > 0).sum() > 1000000
+    acc_p = ora.buffer("acceleration").reshape(-1, 4)[N:, :3]
+    assert np.abs(acc_p).max() > 0, "the pressure acceleration must be non-zero"
+    batches = 3 * 3 * 4 * (N // 64)  # steps x launches x batches per wave x waves
+    assert _pressure_force_fallbacks(hip) <= batches // 1000, "the short division path must be the one that runs"
+    ora.close()
+
+
+def test_pressure_force_slow_path_is_taken_and_exact():
+    """The guards of the short division / square-root path: a liquid particle whose x coordinate is closer to zero than 2^-4 (outside
+    the boundary shell, inside the box) fails `ownOk`, so its wave recomputes every batch with sqrtf and `/` — same bits as the
+    oracle, and the fallback counter says the slow path ran."""
+    sc = scenes.SCENES["tiny_compressed"]()
+    pos = sc["position"].copy()
+    pos[0, 0] = np.float32(0.03)
+    sc["position"] = pos
+    N = sc["cfg"].particleCount
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc)
+    hip.reset_stage_times()
+    for it in range(3):
+        hip.step(it)
+        ora.step()
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "slow path, step %d" % it, FUSED_SKIP)
+    assert canon_ora(ora, N)["pressure"].max() > 0
+    assert _pressure_force_fallbacks(hip) > 0
+    ora.close()
+
+
+def test_config4_box_pressure_active_full_steps_against_oracle():
+    """The config #4 box (16,507,704 particles) with its lattice at 0.85 r0: pressure-active from the first step. Two fused steps,
+    positions, velocities, densities and pressures of every particle against the oracle, bit for bit."""
+    sc = scenes.liquid_box((78.0, 50.0, 470.0), (160, 100, 1000), spacing_in_r0=0.85, mask=0xffffffff)
+    N = sc["cfg"].particleCount
+    assert N == 16507704
+    hip, ora = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16)
+    hip.reset_stage_times()
+    for it in range(2):
+        hip.step(it)
+        ora.step()
+        assert scenes.bits_equal(hip.read_position_buffer(), ora.buffer("position").reshape(-1, 4)[:N]), it
+        assert scenes.bits_equal(hip.read_velocity_buffer(), ora.buffer("velocity").reshape(-1, 4)[:N]), it
+        assert scenes.bits_equal(hip.read_density_buffer(), ora.buffer("rho").reshape(-1)[:N]), it
+        p = ora.buffer("pressure").reshape(-1)[:N]
+        assert scenes.bits_equal(hip.buffer("pressure").reshape(-1)[:N], p), it
+        assert (p > 0).sum() > 10000000, "step %d: pressure-active" % it
+    assert _pressure_force_fallbacks(hip) <= 2 * 3 * 4 * (N // 64) // 1000
+    ora.close()
+
+
+def test_short_division_and_square_root_sequences_are_exact():
+    """sph_fastmath.h replaces IEEE `/` and sqrtf in the hottest arithmetic kernel (k_pressure_force). tools/micro/exact_div_sqrt
+    (built by build(); hipcc also exists on the GPU box) compares them with the compiler's correctly rounded code on the GPU:
+    (i) the square root for EVERY float of [fastD2Min, fastD2Max] of the shipped simulationScale (~8e8 floats) plus the guard's
+    edges, (ii) the division for every mantissa of r at three exponents with numerators placed next to rounding midpoints of the
+    quotient and next to / at floats (~1.8e9 quotients), (iii) 1.07e9 random operand sets. Zero differences."""
+    import subprocess
+    tool_dir = os.path.join(scenes.ROOT, "tools", "micro")
+    exe = os.path.join(tool_dir, "exact_div_sqrt")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", tool_dir, "exact_div_sqrt"])
+    scale = float(np.float32(sphmi.default_config().simulationScale))
+    p = subprocess.run([exe, "suite", repr(scale), "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 6 and all(" 0 differ" in l or " 0 results differ" in l for l in lines[1:]), p.stdout
+    assert "every float of the guarded range" in lines[1]
+
+
+def test_async_position_read_back_overlaps_and_matches():
+    """sph_read_position_async / sph_read_position_wait: the copy of step t runs under step t+1 and the next integrate waits for it
+    on the device. Step-by-step the asynchronously read positions must equal the blocking read of the same step (bit for bit),
+    whether the caller waits at once, a step late, or only at the end; getPosition_cpp() of the simulator waits by itself."""
+    sc = scenes.liquid_box((30.0, 20.0, 30.0), (40, 25, 40), jitter_in_r0=0.05)
+    N = sc["cfg"].particleCount
+    ref = scenes.hip_for(sc)
+    want = []
+    for it in range(6):
+        ref.step(it)
+        want.append(ref.read_position_buffer().copy())
+    ref.close()
+    hip = scenes.hip_for(sc)
+    a, b = np.empty((N, 4), np.float32), np.empty((N, 4), np.float32)
+    hip.step(0); hip.read_position_buffer_async(a); hip.wait_position_buffer()
+    assert scenes.bits_equal(a, want[0])
+    hip.step(1); hip.read_position_buffer_async(a)
+    hip.step(2)                                  # enqueued while the copy of step 1 is in flight: integrate(2) waits for it
+    hip.wait_position_buffer()
+    assert scenes.bits_equal(a, want[1]), "the copy of step 1 must not see step 2's positions"
+    hip.read_position_buffer_async(b)            # step 2, second (page-locked) buffer
+    hip.step(3); hip.read_position_buffer_async(a)   # waits for b's copy first
+    assert scenes.bits_equal(b, want[2])
+    hip.step(4); hip.step(5)
+    hip.wait_position_buffer()
+    assert scenes.bits_equal(a, want[3])
+    assert scenes.bits_equal(hip.read_position_buffer(), want[5])
+    hip.close()
+    sim = sphmi.owPhysicsFluidSimulator(sc["cfg"], sc["position"], sc["velocity"])
+    for it in range(3):
+        sim.simulationStep(async_read_back=True)
+    assert scenes.bits_equal(sim.getPosition_cpp(), want[2])
+
+
+def test_box_that_starts_below_zero_keeps_real_sort_keys():
+    """Wide cell ids with xmin, ymin, zmin < 0 (no particle there): the compacted sort keys of the fused step are only monotone in
+    the real cell ids while their clamps cannot bite, so such a box must sort the real keys — and still follow the oracle."""
+    def build():
+        sc = scenes.liquid_box((82.0, 80.0, 84.0), (30, 20, 30), mask=0xffffffff, jitter_in_r0=0.2, origin_in_r0=(40.0, 30.0, 50.0))
+        sc["cfg"].xmin = sc["cfg"].ymin = sc["cfg"].zmin = -np.float32(sc["cfg"].h)
+        return sc
+    plain = scenes.liquid_box((82.0, 80.0, 84.0), (30, 20, 30), mask=0xffffffff, jitter_in_r0=0.2, origin_in_r0=(40.0, 30.0, 50.0))
+    sc = build()
+    N = sc["cfg"].particleCount
+    hip, ora, hp = scenes.hip_for(sc), scenes.oracle_for(sc, threads=16), scenes.hip_for(plain)
+    assert hp.step_sort_passes() == 2 and hip.step_sort_passes() == 3  # compacted (17 bits, 9-bit digits) vs real keys (20 bits)
+    for it in range(2):
+        hip.step(it)
+        ora.step()
+        assert_same(canon_hip(hip, N), canon_ora(ora, N), "box from -h, step %d" % it, FUSED_SKIP)
+
+
+def test_blown_up_state_stays_reported():
+    """The non-finite-coordinate error is sticky (a caller that ignores one SPH_ERR_INVALID must not continue silently) and a timing
+    reset between the step and the check does not erase it."""
+    sc = scenes.liquid_box((8.0, 8.0, 8.0), (12, 10, 12), jitter_in_r0=0.03)
+    pos = sc["position"].copy()
+    pos[5:10, :3] = pos[200:205, :3]
+    sc["position"] = pos
+    hip = scenes.hip_for(sc)
+    hip.step(0)
+    hip.step(1)
+    hip.reset_stage_times()
+    for _ in range(2):
+        with pytest.raises(sphmi.SphError, match="not finite"):
+            hip.synchronize()
+    with pytest.raises(sphmi.SphError, match="not finite"):
+        hip.read_position_buffer()

@@ -333,3 +333,26 @@ def test_initial_ids_in_any_order_and_unsorted_message_is_rejected():
     be.rebuild(None, bad)
     with pytest.raises(sphmi.SphError):
         be.pack()
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_one_card():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE): bench.py starts its two ranks itself, before any GPU call.
+    The test box has one card, so the ranks share it and the transport falls back to gloo (RCCL refuses two ranks on one
+    device); everything else — per-rank scene slices, slab solvers, overlapped step, exchange, the relayed result line — is the
+    multi-GPU path."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SPHMI_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny_long", "--steps", "4",
+                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["halo"]["owned_sets_partition_all_particles"] is True
+    assert out["dist_backend"] in ("gloo", "nccl") and len(out["devices"]) == 2
+    assert "DIAG" not in out["lib"]["build"] and len(out["lib"]["sha256"]) == 64
+    assert out["roofline"]["frac"] > 0
