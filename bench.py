@@ -442,6 +442,7 @@ def rank_main(args):
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
         p50_ms = per_step[len(per_step) // 2]
         host_pos = np.empty((N, 4), np.float32)
+        k3 = 50  # (the last copy's ~6 ms are not hidden by anything: amortised over 50 steps whatever --steps says)
         solver.read_position_buffer_async(host_pos)  # (page-locks host_pos once, outside the timed loop)
         solver.wait_position_buffer()
         solver.synchronize()
@@ -673,6 +674,8 @@ def extra_dam_break(np, scenes, sphmi, torch, device, stream, evolve=1500):
            "stages_ms": {a: round(ms / 20, 5) for a, (ms, cnt) in st.items() if cnt},
            "find_neighbors_exact_walks_per_step": {"cell_not_staged": int(c[0]) // 20, "list_overflow": int(c[1]) // 20,
                                                    "rows_without_16bit_ids": int(c[2]) // 20, "runs_dropped": int(c[3]) // 20},
+           # (wave, batch of 8 neighbours) pairs of k_pressure_force that left the short division / square-root path, of 3 x 4 per wave
+           "pressure_force_slow_batches_per_step": int(c[8]) // 20, "pressure_force_batches_per_step": 12 * ((n + 63) // 64),
            "mean_y_of_liquid_in_h": round(float(pos[:nl, 1].mean() / sc["cfg"].h), 2),
            "front_x_in_h": round(float(pos[:nl, 0].max() / sc["cfg"].h), 2), "finite": bool(np.isfinite(pos).all())}
     s.close()

@@ -326,7 +326,6 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   d.cellMask = cfg->cellIdMask;
   d.h = cfg->h; d.cellSize = cfg->hashGridCellSize; d.cellSizeInv = cfg->hashGridCellSizeInv;
   d.simScale = cfg->simulationScale; d.simScaleInv = cfg->simulationScaleInv;
-  sph_fast_bounds(cfg->simulationScale, &d.fastD2Min, &d.fastD2Max, &d.fastValueMin);
   d.xmin = cfg->xmin; d.xmax = cfg->xmax; d.ymin = cfg->ymin; d.ymax = cfg->ymax; d.zmin = cfg->zmin; d.zmax = cfg->zmax;
   d.r0 = cfg->r0; d.mass = cfg->mass; d.rho0 = cfg->rho0; d.dt = cfg->timeStep; d.delta = cfg->delta;
   d.gravx = cfg->gravity_x; d.gravy = cfg->gravity_y; d.gravz = cfg->gravity_z;
@@ -350,6 +349,8 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
     d.closeRf = f;
   }
   d.massWpoly6 = ((double)cfg->mass) * cfg->Wpoly6Coefficient;
+  // operand bounds of k_pressure_force's short division / square-root path; the smallest density a kernel can write is hs^6 * mass * Wpoly6
+  sph_fast_bounds(cfg->simulationScale, d.hs, (float)((double)d.hs6 * d.massWpoly6), &d.fastD2Min, &d.fastD2Max, &d.fastValueMin);
   d.massGradW = ((double)cfg->mass) * cfg->gradWspikyCoefficient;
   d.del2W = cfg->del2WviscosityCoefficient;
   d.numElastic = cfg->numOfElasticP; d.elasticOffset = cfg->elasticOffset; d.muscleCount = cfg->muscleCount;

@@ -484,6 +484,9 @@ __device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const
                                          const float2 (&rpj)[PF_BATCH], const int (&jj)[PF_BATCH], float& rx, float& ry, float& rz,
                                          const bool ownOk) {
   bool ok = ownOk;
+  // FAST: value, the three numerators and the three quotients carry the factor 2^40 of sph_fastmath.h (the 0.5 of the numerator
+  // becomes 2^39; the sums take the quotients through fma(q, 2^-40, sum) — the same single rounding as sum + q / 2^40)
+  const float half = FAST ? SPH_FAST_HALF_SCALED : 0.5f;
 #pragma unroll
   for (int k = 0; k < PF_BATCH; k++) {
     const float ex_ = xi.x - xj[k].x, ey_ = xi.y - xj[k].y, ez_ = xi.z - xj[k].z;
@@ -494,18 +497,29 @@ __device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const
     const float r = sq_ * d.simScale;  // == the stored neighborMap distance (sphFluid.cl:131-136,172), which is therefore not read
     // value = -(hs-r)^2*0.5*(p_i+p_j)/rho*_j, or for very close pairs -(hs/4-r)^2*0.5*(rho0*delta)/rho*_j (:1166-1168):
     // the numerator is selected first, so only one IEEE division is spent
-    float num = -(d.hs - r) * (d.hs - r) * 0.5f * (pi_ + rpj[k].y);
-    if (__any(r < d.closeRf)) num = (r < d.closeRf) ? -(hq - r) * (hq - r) * 0.5f * d.rho0delta : num;  // (pairs closer than h/4: rare, so wave-uniformly skipped)
+    float num = -(d.hs - r) * (d.hs - r) * half * (pi_ + rpj[k].y);
+    if (__any(r < d.closeRf)) num = (r < d.closeRf) ? -(hq - r) * (hq - r) * half * d.rho0delta : num;  // (pairs closer than h/4: rare, so wave-uniformly skipped)
     const float value = num / rpj[k].x;
     const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
     const bool use = jj[k] != -1 && r < d.hs;
     const float ax_ = value * vx, ay_ = value * vy, az_ = value * vz;
     float q_[3];
+    // (the division's guard only matters for terms that are used: beyond the support radius, where value is tiny, nothing is added)
+#ifdef PF_GUARD_ALL  // A/B: without the mask (one scalar instruction less per neighbour; twice the — rare — fallbacks)
     if (FAST) ok = sph_div3_by<false>(ax_, ay_, az_, value, d.fastValueMin, r, q_) && ok;
+#else
+    if (FAST) ok = (sph_div3_by<false>(ax_, ay_, az_, value, d.fastValueMin, r, q_) || !use) && ok;
+#endif
     else { q_[0] = ax_ / r; q_[1] = ay_ / r; q_[2] = az_ / r; }
-    rx = use ? rx + q_[0] : rx;
-    ry = use ? ry + q_[1] : ry;
-    rz = use ? rz + q_[2] : rz;
+    if (FAST) {
+      rx = use ? __builtin_fmaf(q_[0], SPH_FAST_UNSCALE, rx) : rx;
+      ry = use ? __builtin_fmaf(q_[1], SPH_FAST_UNSCALE, ry) : ry;
+      rz = use ? __builtin_fmaf(q_[2], SPH_FAST_UNSCALE, rz) : rz;
+    } else {
+      rx = use ? rx + q_[0] : rx;
+      ry = use ? ry + q_[1] : ry;
+      rz = use ? rz + q_[2] : rz;
+    }
   }
   return !FAST || !__any(!ok);
 }

@@ -33,23 +33,31 @@ __device__ __forceinline__ float rnd_float(uint64_t& s, int elo, int ehi, bool s
   return __uint_as_float(bits);
 }
 
+// The data flow of k_pressure_force's fast path (sph_pcisph.hip, pf_batch<true>) against its IEEE path (pf_batch<false>), one
+// neighbour per iteration: d2 -> r = sqrt(d2) * scale; value = -(hs - r)^2 * 0.5 * (p_i + p_j) / rho_j (fast: 2^39 instead of 0.5, so
+// everything downstream carries 2^40); numerators value * v_k; quotients by r; sum + quotient (fast: fma(q, 2^-40, sum)).
 __global__ void k_check(uint64_t seed, int iters, unsigned long long* bad, unsigned long long* slow, float* example) {
   uint64_t s = seed * 0x100000001b3ull + (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9e3779b97f4a7c15ull;
   unsigned long long nb = 0, ns = 0;
   for (int it = 0; it < iters; it++) {
-    // the kernel's data flow: a length scale, the bounds the host derives from it, d2 -> r = sqrt(d2) * scale -> numerators value * v_k
     const float scale = rnd_float(s, -26, 0, false);
-    float d2Min, d2Max, valueMin;
-    sph_fast_bounds(scale, &d2Min, &d2Max, &valueMin);
     const float x = rnd_float(s, SPH_FAST_S_EXP_LO - 4, SPH_FAST_S_EXP_HI + 3, false);  // also beyond both ends of the bounds
+    const float wantS = sqrtf(x);
+    const float r = wantS * scale;
+    // the support radius: usually a few r, sometimes within a few ulps .. percent of r (value then gets tiny: the guard's edge)
+    const uint32_t hk = rng(s);
+    const float hs = (hk & 1u) ? r * (1.f + __uint_as_float((uint32_t)(127 - (int)((hk >> 1) % 24u)) << 23)) : r * (1.f + 4.f * rnd_float(s, -3, 0, false));
+    float d2Min, d2Max, valueMin;
+    sph_fast_bounds(scale, hs, 1.0f, &d2Min, &d2Max, &valueMin);
     float sq;
     const bool fs = sph_sqrt_fast(x, d2Min, d2Max, &sq);
-    const float wantS = sqrtf(x);
     if (!fs) ns++;
     else if (__float_as_uint(sq) != __float_as_uint(wantS)) { if (nb == 0) { example[0] = x; example[1] = 0.f; example[2] = sq; example[3] = wantS; } nb++; }
     if (!fs) continue;  // (the kernel recomputes such a batch with the compiler's code)
-    const float r = wantS * scale;
-    const float value = (rng(s) & 63u) == 0 ? 0.f : rnd_float(s, -120, 62, true);
+    const float P = (rng(s) & 63u) == 0 ? 0.f : rnd_float(s, -40, 30, false);   // p_i + p_j >= 0
+    const float rho = rnd_float(s, -10, 20, false);                              // >= rhoMin = 1 would be the solver's guarantee; smaller is harsher
+    const float num = -(hs - r) * (hs - r) * 0.5f * P, numS = -(hs - r) * (hs - r) * SPH_FAST_HALF_SCALED * P;
+    const float value = num / rho, valueS = numS / rho;
     float v[3];
     for (int c = 0; c < 3; c++) {
       const uint32_t pick = rng(s) & 15u;
@@ -57,18 +65,20 @@ __global__ void k_check(uint64_t seed, int iters, unsigned long long* bad, unsig
       v[c] = pick == 0 ? 0.f : rnd_float(s, 0, 0, true) * r * __uint_as_float((uint32_t)(127 - down) << 23) * (pick == 1 ? 1.f : 0.999f);
     }
     float q[3];
-    bool fast = sph_div3_by<false>(value * v[0], value * v[1], value * v[2], value, valueMin, r, q);
-    for (int c = 0; c < 3; c++) {  // the caller's precondition: numerators zero or at least 2^SPH_FAST_A_EXP_LO
-      const float a = fabsf(value * v[c]);
+    bool fast = sph_div3_by<false>(valueS * v[0], valueS * v[1], valueS * v[2], valueS, valueMin, r, q);
+    for (int c = 0; c < 3; c++) {  // the caller's precondition: scaled numerators zero or at least 2^SPH_FAST_A_EXP_LO
+      const float a = fabsf(valueS * v[c]);
       if (a != 0.f && a < __uint_as_float((uint32_t)(SPH_FAST_A_EXP_LO + 127) << 23)) fast = false;
     }
     if (!fast) { ns++; continue; }
     for (int c = 0; c < 3; c++) {
       const float a = value * v[c];
-      const float want = a / r;
+      const float sum = (rng(s) & 3u) == 0 ? 0.f : rnd_float(s, -60, 40, true);
+      const float want = sum + a / r;
+      const float got = __builtin_fmaf(q[c], SPH_FAST_UNSCALE, sum);
       // (+0 and -0 are interchangeable for the kernel: the terms are added to sums that are never -0)
-      const bool same = __float_as_uint(q[c]) == __float_as_uint(want) || (q[c] == 0.f && want == 0.f);
-      if (!same) { if (nb == 0) { example[0] = a; example[1] = r; example[2] = q[c]; example[3] = want; } nb++; }
+      const bool same = __float_as_uint(got) == __float_as_uint(want) || (got == 0.f && want == 0.f);
+      if (!same) { if (nb == 0) { example[0] = a; example[1] = r; example[2] = got; example[3] = want; } nb++; }
     }
   }
   if (nb) atomicAdd(bad, nb);
@@ -159,7 +169,7 @@ int main(int argc, char** argv) {
     const float scale = (float)atof(argv[2]);
     rounds = argc > 3 ? atoi(argv[3]) : 1;
     float d2Min, d2Max, valueMin;
-    sph_fast_bounds(scale, &d2Min, &d2Max, &valueMin);
+    sph_fast_bounds(scale, 3.34f * scale, 100.f, &d2Min, &d2Max, &valueMin);
     uint32_t lo, hi; memcpy(&lo, &d2Min, 4); memcpy(&hi, &d2Max, 4);
     printf("simulationScale %a: guarded d2 range [%a, %a] = %llu floats, valueMin %a\n", scale, d2Min, d2Max, (unsigned long long)hi - lo + 1, valueMin);
     if (!(d2Min < d2Max)) { printf("empty range\n"); return 1; }
