@@ -45,7 +45,7 @@ __host__ __device__ static inline void sph_fast_bounds(float simulationScale, fl
   if (lo < ldexp(1.0, SPH_FAST_S_EXP_LO + 1)) lo = ldexp(1.0, SPH_FAST_S_EXP_LO + 1);
   if (hi > ldexp(1.0, SPH_FAST_S_EXP_HI - 1)) hi = ldexp(1.0, SPH_FAST_S_EXP_HI - 1);
   // (hScaled >= 2^-30: (hs - r)^2, a square of a difference of floats of that size, and its half are then normal numbers)
-  const bool sane = s > 0.0 && lo < hi && rhoMin >= 0x1p-40f && rhoMin <= 0x1p60f && hScaled >= 0x1p-30f && hScaled <= 1.f;
+  const bool sane = s > 0.0 && lo < hi && rhoMin >= 0x1p-40f && 33.f * rhoMin <= 0x1p20f && hScaled >= 0x1p-30f && hScaled <= 1.f;
   *d2Min = sane ? (float)lo : INFINITY;
   *d2Max = sane ? (float)hi : 0.f;
   // 2 * 2^(SPH_FAST_A_EXP_LO - SPH_FAST_COORD_EXP_LO + 24) / scale, on the scaled value
@@ -86,6 +86,21 @@ __device__ __forceinline__ bool sph_div3_by(float a0, float a1, float a2, float 
     q[k] = __builtin_fmaf(r1, y, t);
   }
   return ok;  // (the results are computed either way — no branch — and are meaningless when this is false)
+}
+
+// a / d by the same short sequence, one numerator. k_pressure_force: value = num / rho*_j. No guard of its own is needed there:
+// rho* is max(sum, hs^6) * mass * Wpoly6 with sum <= 32 hs^6, i.e. inside [rhoMin, 33 rhoMin] for ANY input (sph_fast_bounds checks
+// that interval against [2^-40, 2^20] once); a numerator too small for exact residuals (< 2^-100) gives a quotient far below the
+// valueMin that sph_div3_by checks next, zero gives exactly zero, and inf / NaN fail that check too.
+__device__ __forceinline__ float sph_div1_by(float a, float d) {
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, y0, 1.f);
+  const float y = __builtin_fmaf(e, y0, y0);
+  float t = a * y;
+  const float r0 = __builtin_fmaf(-d, t, a);
+  t = __builtin_fmaf(r0, y, t);
+  const float r1 = __builtin_fmaf(-d, t, a);
+  return __builtin_fmaf(r1, y, t);
 }
 
 // *out = sqrtf(x), correctly rounded, for x in the guarded range: v_sqrt_f32 (1 ulp) and the two one-ulp neighbours checked by residual

@@ -499,17 +499,18 @@ __device__ __forceinline__ bool pf_batch(const SphDev& d, const float4 xi, const
     // the numerator is selected first, so only one IEEE division is spent
     float num = -(d.hs - r) * (d.hs - r) * half * (pi_ + rpj[k].y);
     if (__any(r < d.closeRf)) num = (r < d.closeRf) ? -(hq - r) * (hq - r) * half * d.rho0delta : num;  // (pairs closer than h/4: rare, so wave-uniformly skipped)
+#ifdef PF_IEEE_VALUE  // A/B: the compiler's division for value (13-15 instructions instead of 8)
     const float value = num / rpj[k].x;
+#else
+    const float value = FAST ? sph_div1_by(num, rpj[k].x) : num / rpj[k].x;
+#endif
     const float vx = (xi.x - xj[k].x) * d.simScale, vy = (xi.y - xj[k].y) * d.simScale, vz = (xi.z - xj[k].z) * d.simScale;
     const bool use = jj[k] != -1 && r < d.hs;
     const float ax_ = value * vx, ay_ = value * vy, az_ = value * vz;
     float q_[3];
-    // (the division's guard only matters for terms that are used: beyond the support radius, where value is tiny, nothing is added)
-#ifdef PF_GUARD_ALL  // A/B: without the mask (one scalar instruction less per neighbour; twice the — rare — fallbacks)
-    if (FAST) ok = sph_div3_by<false>(ax_, ay_, az_, value, d.fastValueMin, r, q_) && ok;
-#else
+    // (the division's guard only matters for terms that are used: beyond the support radius, where value is tiny, nothing is added.
+    // Guarding every lane and dropping unused terms by scaling them with 0 — one select instead of three — was measured: no change)
     if (FAST) ok = (sph_div3_by<false>(ax_, ay_, az_, value, d.fastValueMin, r, q_) || !use) && ok;
-#endif
     else { q_[0] = ax_ / r; q_[1] = ay_ / r; q_[2] = az_ / r; }
     if (FAST) {
       rx = use ? __builtin_fmaf(q_[0], SPH_FAST_UNSCALE, rx) : rx;
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pressure_force(SphDev d, int nblo
   // masked accumulation (a skipped term leaves the sum untouched, exactly as the reference's `if`).
   // The distances are NOT read: r_ij is recomputed from the two position records this kernel has anyway, with the expression
   // findNeighbors stored it with (sphFluid.cl:131-136,172; IEEE sqrt) — bit-identical, and 128 of the 272 bytes the kernel
-  // streamed per particle are gone (1.24 -> 1.17 ms per launch at 16.5 M particles).
+  // streamed per particle are gone (1.24 -> 1.17 ms per launch at 16.5 M particles; re-measured in round 3 with the short
+  // arithmetic in place: reading the rows instead of taking the square root is 1.26 vs 1.00 ms per launch).
   uint2 v16[8];
 #pragma unroll
   for (int g = 0; g < 8; g++) v16[g] = t.vec16(g);

@@ -57,7 +57,7 @@ __global__ void k_check(uint64_t seed, int iters, unsigned long long* bad, unsig
     const float P = (rng(s) & 63u) == 0 ? 0.f : rnd_float(s, -40, 30, false);   // p_i + p_j >= 0
     const float rho = rnd_float(s, -10, 20, false);                              // >= rhoMin = 1 would be the solver's guarantee; smaller is harsher
     const float num = -(hs - r) * (hs - r) * 0.5f * P, numS = -(hs - r) * (hs - r) * SPH_FAST_HALF_SCALED * P;
-    const float value = num / rho, valueS = numS / rho;
+    const float value = num / rho, valueS = sph_div1_by(numS, rho);  // (the kernel's fast path: short sequence, no guard of its own)
     float v[3];
     for (int c = 0; c < 3; c++) {
       const uint32_t pick = rng(s) & 15u;
