@@ -366,6 +366,8 @@ def rank_main(args):
         k2 = max(5, min(args.steps, 20))
         for _ in range(k2):
             stepper.step(it); it += 1
+        if decomposition is not None:
+            decomposition.finish()  # (collects the last asynchronous exchange: the local particle count)
         st = solver.stage_times()
         solver.set_stage_timing(False)
         stages_ms = {k: round(ms / k2, 5) for k, (ms, cnt) in st.items() if cnt}
@@ -409,6 +411,7 @@ def rank_main(args):
     # every owned particle must be finite — a silent halo failure would show here.
     partition_ok = None
     if decomposition is not None:
+        decomposition.finish()
         pos_l, vel_l, gid_l, owned_l = solver.slab_read()
         m = owned_l.astype(bool)
         stats = torch.tensor([float(m.sum()), float(np.isfinite(pos_l[m]).all() and np.isfinite(vel_l[m]).all()),
@@ -533,6 +536,8 @@ def rank_main(args):
                            "bytes_sent_per_step_per_rank": (per_rank[:, 1] / max(1, it)).astype(int).tolist(),
                            "exchange_host_ms_per_step_per_rank": [round(v * 1e3 / max(1, it), 4) for v in per_rank[:, 2]],
                            "p2p_groups_per_step_rank0": round(decomposition.transfers / max(1, it), 3),
+                           "record_bytes": 4 * decomposition.rec, "boundary_shell": "static (kept per rank, never sent)",
+                           "host_waits_per_step": 1 if decomposition._can_run_async() else 3,
                            "owned_sets_partition_all_particles": partition_ok}
         print(json.dumps(out), flush=True)
     beat("done")

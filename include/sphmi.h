@@ -164,8 +164,8 @@ int sph_step_sort_passes(sph_solver* s);
  * cover the 6 neighbour hops (6 x 31h/30) that one PCISPH step propagates information, so owned particles get bit-identical
  * results to a single-solver run; the local arrays are kept sorted by global id so that the within-cell order (ascending
  * orig id) is the global one. Requires cellIdMask = 0xffffffff.
- * Message = n records of 9 words: position (x,y,z,type), velocity (vx,vy,vz,w), global id. All pointers below are DEVICE
- * pointers on the solver's device. */
+ * Message = n records of 9 words: position (x,y,z,type), velocity (vx,vy,vz,w), global id (or 7 words, see
+ * sph_slab_set_record_format). All pointers below are DEVICE pointers on the solver's device. */
 typedef struct sph_slab {
   int32_t layerLo, layerHi;   /* owned cell layers along z: cz = (int)(z * hashGridCellSizeInv) */
   int32_t ghostLayers;        /* W */
@@ -173,6 +173,7 @@ typedef struct sph_slab {
   int32_t globalIdBits;       /* bit length of the largest global id */
 } sph_slab;
 #define SPH_SLAB_RECORD_WORDS 9
+#define SPH_SLAB_COMPACT_WORDS 7 /* x, y, z, vx, vy, vz, global id: see sph_slab_set_record_format */
 int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t* globalIds /* host, particleCount entries */);
 /* counts[0] = authoritative particles kept, counts[1] / counts[2] = records written to msgDown / msgUp (each has room for
  * `capRecords`), every list in ascending global-id order (order-preserving compaction of the sorted local set).
@@ -193,6 +194,25 @@ int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDown, const v
  * sph_slab_rebuild waits for the step and takes the kept count from it. capRecords overflow is reported by sph_slab_step_messages. */
 int sph_slab_step_begin(sph_solver* s, int iterationCount, void* frameDown, void* frameUp, int32_t capRecords);
 int sph_slab_step_messages(sph_solver* s, int32_t counts[2]);
+/* The same rebuild with NO host round trip: frameDown / frameUp are complete received frames `[payload words | payload]` with room
+ * for capXRecords records (NULL where there is no neighbour), the kept count is taken where the preceding pack left it on the
+ * device. Everything is enqueued and the call returns; the new particle count reaches the host with sph_slab_rebuild_finish
+ * (blocking; also done implicitly by the next call that needs it): counts = kept, records from below, from above, and
+ * counts[3] = 1 if NOTHING was merged because a frame announced more records than its buffer holds — fetch the rest and call
+ * sph_slab_rebuild with the complete messages. A total beyond the solver's capacity is SPH_ERR_SIZE. */
+int sph_slab_rebuild_framed(sph_solver* s, const void* frameDown, int32_t capDownRecords, const void* frameUp, int32_t capUpRecords);
+int sph_slab_rebuild_finish(sph_solver* s, int32_t counts[4]);
+/* Boundary particles never move: every solver keeps the boundary particles of its ghost layers from sph_slab_init on, and no
+ * message ever carries one. The other particles' records can drop two more words: *typeBits = the position.w bit pattern common
+ * to all non-boundary particles this solver was created with, provided their velocity.w is +0 (neither value ever changes);
+ * 0 = it holds none, 0xffffffff = not uniform. When EVERY rank reports the same pattern (or 0), all of them may call
+ * sph_slab_set_record_format(s, SPH_SLAB_COMPACT_WORDS, pattern) before the first pack: records are then 7 words
+ * (x, y, z, vx, vy, vz, global id), 28 instead of 36 bytes. Default: SPH_SLAB_RECORD_WORDS. */
+int sph_slab_liquid_signature(sph_solver* s, uint32_t* typeBits);
+int sph_slab_set_record_format(sph_solver* s, int32_t recordWords, uint32_t typeBits);
+/* Make the solver's stream wait for a hipEvent_t recorded on another stream (e.g. behind the RCCL receive on the caller's
+ * communication stream) — stream-to-stream, the host does not wait. */
+int sph_stream_wait_event(sph_solver* s, void* hipEvent);
 int sph_particle_count(sph_solver* s);
 /* Blocking read of the local set in its current order: positions, velocities (4 floats each), global ids and the
  * ownership flag (1 = in the owned layers when the set was last rebuilt); arrays sized sph_particle_count(). */

@@ -236,6 +236,7 @@ static void free_all(sph_solver* s) {
   if (s->evCopyDone) hipEventDestroy(s->evCopyDone);
   if (s->copyStream) hipStreamDestroy(s->copyStream);
   if (s->slabMsgEvent) hipEventDestroy(s->slabMsgEvent);
+  if (s->slabRebuildEvent) hipEventDestroy(s->slabRebuildEvent);
   if (s->ownStream && s->stream) hipStreamDestroy(s->stream);
   free(s->pending);
   free(s->hostScratch);
@@ -281,6 +282,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   if (cfg->maxIteration < 1) { sph_set_error("maxIteration must be >= 1"); return SPH_ERR_INVALID; }
   if (!(cfg->h > 0.f) || !(cfg->hashGridCellSize > 0.f)) { sph_set_error("h / hashGridCellSize must be positive"); return SPH_ERR_INVALID; }
 
+  uint32_t liquidSig = 0u;
   // Input sanity the reference does not have. Non-finite coordinates make every particle hash into one cell (a quadratic
   // search); in wide mode a coordinate outside the box gives a cell id outside [0, gridCellCount), and the radix sort only
   // orders the bits a valid id can have. (Reference mode keeps the reference's behaviour for out-of-box input: ids alias.)
@@ -289,6 +291,12 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   {
     const bool wide = cfg->cellIdMask == 0xffffffffu;
     for (int i = 0; i < N; i++) {
+      if ((int)position[4 * (size_t)i + 3] != SPH_BOUNDARY_PARTICLE && liquidSig != 0xffffffffu) {  // (see sph_slab_liquid_signature)
+        uint32_t tb, wb;
+        memcpy(&tb, &position[4 * (size_t)i + 3], 4); memcpy(&wb, &velocity[4 * (size_t)i + 3], 4);
+        if (wb != 0u || tb == 0u || tb == 0xffffffffu || (liquidSig != 0u && liquidSig != tb)) liquidSig = 0xffffffffu;
+        else liquidSig = tb;
+      }
       const float x = position[4 * (size_t)i], y = position[4 * (size_t)i + 1], z = position[4 * (size_t)i + 2];
       const bool finite = std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
       const bool inside = x >= cfg->xmin && x <= cfg->xmax && y >= cfg->ymin && y <= cfg->ymax && z >= cfg->zmin && z <= cfg->zmax;
@@ -315,6 +323,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   sph_solver* s = new sph_solver();
   memset((void*)s, 0, sizeof(*s));
   s->cfg = *cfg;
+  s->liquidSig = liquidSig;
   if (cfg->stream) { s->stream = (hipStream_t)cfg->stream; s->ownStream = false; }
   else {
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -372,7 +381,7 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
   A(d.nbrId, mapN); A(d.nbrDist, mapN); A(d.nbr16, mapN); A(d.nbrBase, (size_t)s->capTiles * 64);
   A(d.rho, n);
   A(s->blockHist, (size_t)SPH_SORT_MAX_DIGITS * s->maxSortBlocks + SPH_SORT_MAX_DIGITS);  // block histograms + digit totals
-  A(d.gid, n); A(d.owned, n); A(s->slabCounts, 12);
+  A(d.gid, n); A(d.owned, n); A(s->slabCounts, SPH_SLAB_COUNT_WORDS);
   A(d.dbg, SPH_DBG_WORDS);
   float* binU = nullptr;
   A(binU, 64);
@@ -429,7 +438,10 @@ extern "C" int sph_create(const sph_config* cfg, const float* position, const fl
 }
 
 // ---------------------------------------------------------------------------------------------- stages
-#define ENTER(s) do { if (!(s)) { sph_set_error("null solver"); return SPH_ERR_INVALID; } SPH_HIP(hipSetDevice((s)->cfg.device)); } while (0)
+static int slab_finish(sph_solver* s, int32_t counts[4]);
+// (a rebuild whose particle count is still on its way to the host — sph_slab_rebuild_framed — is finished first)
+#define ENTER_RAW(s) do { if (!(s)) { sph_set_error("null solver"); return SPH_ERR_INVALID; } SPH_HIP(hipSetDevice((s)->cfg.device)); } while (0)
+#define ENTER(s) do { ENTER_RAW(s); if ((s)->slabRebuildPending) { const int rcf_ = slab_finish((s), nullptr); if (rcf_ != SPH_OK) return rcf_; } } while (0)
 
 extern "C" int sph_run_clear_buffers(sph_solver* s) {
   ENTER(s);
@@ -947,7 +959,10 @@ extern "C" int sph_read_neighbor_rows(sph_solver* s, int32_t first, int32_t coun
 }
 
 // ---------------------------------------------------------------------------------------------- slab decomposition
-extern "C" int sph_particle_count(sph_solver* s) { return s ? s->d.N : SPH_ERR_INVALID; }
+extern "C" int sph_particle_count(sph_solver* s) {
+  ENTER(s);
+  return s->d.N;
+}
 
 extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t* globalIds) {
   ENTER(s);
@@ -960,14 +975,15 @@ extern "C" int sph_slab_init(sph_solver* s, const sph_slab* slab, const uint32_t
     return SPH_ERR_INVALID;
   }
   s->slab = *slab; s->hasSlab = true; s->slabKept = -1; s->slabStepPending = false;
-  if (!s->slabHost) SPH_HIP(hipHostMalloc((void**)&s->slabHost, sizeof(uint32_t) * 12, hipHostMallocDefault));
+  if (!s->slabHost) SPH_HIP(hipHostMalloc((void**)&s->slabHost, sizeof(uint32_t) * SPH_SLAB_COUNT_WORDS, hipHostMallocDefault));
   if (!s->slabMsgEvent) SPH_HIP(hipEventCreateWithFlags(&s->slabMsgEvent, hipEventDisableTiming));
+  if (!s->slabRebuildEvent) SPH_HIP(hipEventCreateWithFlags(&s->slabRebuildEvent, hipEventDisableTiming));
   SPH_HIP(hipMemcpyAsync(s->d.gid, globalIds, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyHostToDevice, s->stream));
   // ownership flags from the initial positions: reuse the rebuild path with nothing received
   SPH_HIP(hipMemcpyAsync(s->d.sortedPos, s->d.posOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
   SPH_HIP(hipMemcpyAsync(s->d.sortedVel, s->d.velOrig, sizeof(float4) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
   SPH_HIP(hipMemcpyAsync(s->d.keys, s->d.gid, sizeof(uint32_t) * (size_t)s->d.N, hipMemcpyDeviceToDevice, s->stream));
-  SPH_HIP(hipMemsetAsync(s->slabCounts, 0, sizeof(uint32_t) * 12, s->stream));
+  SPH_HIP(hipMemsetAsync(s->slabCounts, 0, sizeof(uint32_t) * SPH_SLAB_COUNT_WORDS, s->stream));
   int rc = sphk_slab_sort_rebuild(s, s->d.N);
   if (rc != SPH_OK) return rc;
   SPH_HIP(hipStreamSynchronize(s->stream));
@@ -1066,6 +1082,90 @@ extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDo
   const long long total = (long long)kept + nDown + nUp;
   if (total > s->capacity || total <= 0) { sph_set_error("slab holds %lld particles after the exchange, capacity %d", total, s->capacity); return SPH_ERR_SIZE; }
   return sphk_slab_rebuild(s, (const uint32_t*)recvDown, nDown, (const uint32_t*)recvUp, nUp, kept);
+}
+
+// ---- the rebuild without a host round trip. The frames are what RCCL delivered: [payload words | payload]; the kept count is
+// where the pack left it on the device. Everything is enqueued at once; the totals come back through pinned memory and
+// slab_finish (called by sph_slab_rebuild_finish, or implicitly by the next entry point) sets the new particle count.
+extern "C" int sph_slab_rebuild_framed(sph_solver* s, const void* frameDown, int32_t capDownRecords, const void* frameUp,
+                                       int32_t capUpRecords) {
+  ENTER(s);
+  if (!s->hasSlab || capDownRecords < 0 || capUpRecords < 0) { sph_set_error("sph_slab_rebuild_framed: bad arguments"); return SPH_ERR_INVALID; }
+  const uint32_t* keptPtr;
+  if (s->slabStepPending) keptPtr = s->slabCounts + 8;       // overlapped step: the kept pass of sph_slab_step_begin
+  else if (s->slabKept >= 0) keptPtr = s->slabCounts + 0;    // sph_slab_pack / sph_slab_pack_framed
+  else { sph_set_error("sph_slab_rebuild_framed without a preceding pack"); return SPH_ERR_ORDER; }
+  s->slabCapDown = frameDown ? capDownRecords : 0; s->slabCapUp = frameUp ? capUpRecords : 0;
+  int rc = sphk_slab_rebuild_framed(s, (const uint32_t*)frameDown, s->slabCapDown, (const uint32_t*)frameUp, s->slabCapUp, keptPtr, s->slabCounts + 12);
+  if (rc != SPH_OK) return rc;
+  SPH_HIP(hipMemcpyAsync(s->slabHost + 12, s->slabCounts + 12, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s->stream));
+  SPH_HIP(hipEventRecord(s->slabRebuildEvent, s->stream));
+  s->slabRebuildPending = true;
+  return SPH_OK;
+}
+
+// counts: kept, records from below, records from above, and 1 if NOTHING was merged because a frame announced more records than
+// its buffer had room for (the caller fetches the missing part and rebuilds with sph_slab_rebuild; the state is untouched).
+static int slab_finish(sph_solver* s, int32_t counts[4]) {
+  SPH_HIP(hipEventSynchronize(s->slabRebuildEvent));
+  s->slabRebuildPending = false;
+  if (s->slabStepPending) {  // the flags that came back with the end of the overlapped step
+    s->slabStepPending = false;
+    if (s->slabHost[3]) {
+      SPH_HIP(hipMemsetAsync(s->slabCounts + 3, 0, sizeof(uint32_t), s->stream));
+      sph_set_error("a halo message passed to the last rebuild was not sorted by global id");
+      return SPH_ERR_INVALID;
+    }
+    if (s->slabHost[7]) return slab_motion_error(s, s->slabHost[7]);
+  }
+  const int kept = (int)s->slabHost[12], nDown = (int)s->slabHost[13], nUp = (int)s->slabHost[14];
+  const bool nothing = s->slabHost[15] != 0u;
+  if (counts) { counts[0] = kept; counts[1] = nDown; counts[2] = nUp; counts[3] = nothing ? 1 : 0; }
+  if (nothing) {
+    if (nDown <= s->slabCapDown && nUp <= s->slabCapUp) {
+      sph_set_error("slab holds %lld particles after the exchange, capacity %d", (long long)kept + nDown + nUp, s->capacity);
+      return SPH_ERR_SIZE;
+    }
+    s->slabKept = kept;  // the frames were too short: sph_slab_rebuild with the complete messages finishes the job
+    if (!counts) { sph_set_error("a halo frame announced %d / %d records, room for %d / %d", nDown, nUp, s->slabCapDown, s->slabCapUp); return SPH_ERR_SIZE; }
+    return SPH_OK;
+  }
+  s->slabKept = -1;
+  s->d.N = kept + nDown + nUp;
+  s->progress = 0;
+  return SPH_OK;
+}
+
+extern "C" int sph_slab_rebuild_finish(sph_solver* s, int32_t counts[4]) {
+  ENTER_RAW(s);
+  if (!counts) { sph_set_error("sph_slab_rebuild_finish: null argument"); return SPH_ERR_INVALID; }
+  if (!s->slabRebuildPending) { sph_set_error("sph_slab_rebuild_finish without sph_slab_rebuild_framed"); return SPH_ERR_ORDER; }
+  return slab_finish(s, counts);
+}
+
+extern "C" int sph_slab_liquid_signature(sph_solver* s, uint32_t* typeBits) {
+  ENTER(s);
+  if (!typeBits) return SPH_ERR_INVALID;
+  *typeBits = s->liquidSig;
+  return SPH_OK;
+}
+
+extern "C" int sph_slab_set_record_format(sph_solver* s, int32_t recordWords, uint32_t typeBits) {
+  ENTER(s);
+  if (recordWords != SPH_SLAB_RECORD_WORDS && recordWords != SPH_SLAB_COMPACT_WORDS) { sph_set_error("record words must be %d or %d", SPH_SLAB_RECORD_WORDS, SPH_SLAB_COMPACT_WORDS); return SPH_ERR_INVALID; }
+  if (recordWords == SPH_SLAB_COMPACT_WORDS && (s->liquidSig == 0xffffffffu || (s->liquidSig != 0u && s->liquidSig != typeBits))) {
+    sph_set_error("compact halo records need one common type word and velocity.w == 0 for every non-boundary particle");
+    return SPH_ERR_INVALID;
+  }
+  s->slabRecWords = recordWords; s->slabTypeBits = typeBits;
+  return SPH_OK;
+}
+
+extern "C" int sph_stream_wait_event(sph_solver* s, void* hipEvent) {
+  ENTER(s);
+  if (!hipEvent) return SPH_ERR_INVALID;
+  SPH_HIP(hipStreamWaitEvent(s->stream, (hipEvent_t)hipEvent, 0));
+  return SPH_OK;
 }
 
 extern "C" int sph_slab_read(sph_solver* s, float* position4, float* velocity4, uint32_t* globalIds, uint32_t* owned) {

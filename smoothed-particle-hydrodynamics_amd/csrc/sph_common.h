@@ -23,6 +23,7 @@
 #define SPH_MAXN 32
 #define SPH_RSEG 30  // radius_segments, sphFluid.cl:116
 #define SPH_DBG_WORDS 32  // diagnostic counters (SphDev::dbg)
+#define SPH_SLAB_COUNT_WORDS 24
 #define SPH_SORT_MAX_DIGITS 512   // radix digits per pass: 256 (8 bits) or 512 (9 bits)
 
 struct SphDev {  // what the kernels see; passed by value
@@ -81,13 +82,22 @@ struct sph_solver {
   int capacity;              // particles the buffers are sized for (>= d.N)
   int capTiles;              // ceil(capacity/64)
   sph_slab slab; bool hasSlab;
-  uint32_t* slabCounts;      // device, 12 words: [0..2] kept / down / up of sph_slab_pack, [3] unsorted-message flag,
-                             // [4..6] and [8..10] the same triples of the overlapped step's message / kept passes
+  uint32_t* slabCounts;      // device, SPH_SLAB_COUNT_WORDS words: [0..2] kept / down / up of sph_slab_pack, [3] unsorted-message flag,
+                             // [4..6] and [8..10] the same triples of the overlapped step's message / kept passes, [7] owned
+                             // particles that moved more than a layer, [12..15] totals of sph_slab_rebuild_framed (kept, from
+                             // below, from above, 1 = nothing merged)
   uint32_t* slabHost;        // pinned host mirror of slabCounts (overlapped step)
   hipEvent_t slabMsgEvent;   // recorded when the messages of the overlapped step are packed
   bool slabStepPending;      // sph_slab_step_begin issued, rebuild not yet done
   int slabCapRecords;        // frame capacity given to sph_slab_step_begin
   int slabKept;              // host copy of the kept count of the last sph_slab_pack (-1: none pending)
+  int slabRecWords;          // words per message record: 9 (full) or 7 (compact); 0 = 9
+  uint32_t slabTypeBits;     // compact records: the type word every non-boundary particle carries
+  uint32_t liquidSig;        // from sph_create: common position.w bits of the non-boundary particles with velocity.w == +0,
+                             // 0 = there are none, 0xffffffff = not uniform
+  bool slabRebuildPending;   // sph_slab_rebuild_framed issued: the particle count is still on its way to the host
+  hipEvent_t slabRebuildEvent;
+  int slabCapDown, slabCapUp;  // records the frames given to sph_slab_rebuild_framed had room for
   // radix-sort workspace
   uint32_t* blockHist;       // [SPH_SORT_MAX_DIGITS][maxSortBlocks] block histograms + SPH_SORT_MAX_DIGITS digit totals
   int maxSortBlocks;
@@ -213,6 +223,8 @@ int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRec
 SphDev sph_ranged_layers(const sph_solver* s, long long loLayer, long long hiLayer);  // launch restricted to cell layers [lo, hi)
 int sphk_pressure_force_layers(sph_solver* s, int fuse, long long loLayer, long long hiLayer);
 int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept);  // 3-way merge
+int sphk_slab_rebuild_framed(sph_solver* s, const uint32_t* frameDown, int capDown, const uint32_t* frameUp, int capUp,
+                             const uint32_t* keptPtr, uint32_t* totals);  // every length read on the device; d.N is left alone
 int sphk_slab_sort_rebuild(sph_solver* s, int total);  // staging area in any order -> local set sorted by global id
 // sph_elastic.hip
 int sphk_elastic(sph_solver* s);

@@ -4,17 +4,41 @@
 // messages with RCCL send/recv (smoothed-particle-hydrodynamics_amd/sphmi/slab.py).
 #include "sph_common.h"
 
-#define REC SPH_SLAB_RECORD_WORDS
+// Message record. Full form (SPH_SLAB_RECORD_WORDS = 9 words): position (x, y, z, type), velocity (vx, vy, vz, w), global id.
+// Compact form (SPH_SLAB_COMPACT_WORDS = 7 words: x, y, z, vx, vy, vz, global id), used when every rank has verified that all
+// non-boundary particles carry the same type word and velocity.w == +0 (sph_slab_liquid_signature / sph_slab_set_record_format):
+// neither ever changes (integrate copies position.w and maps velocity.w = 0 to 0), so they travel as one constant.
+struct RecFmt { int words; uint32_t typeBits; };
 
-__device__ __forceinline__ void put_record(uint32_t* msg, uint32_t j, const float4 p, const float4 v, uint32_t g) {
-  uint32_t* r = msg + (size_t)j * REC;
-  r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y); r[2] = __float_as_uint(p.z); r[3] = __float_as_uint(p.w);
-  r[4] = __float_as_uint(v.x); r[5] = __float_as_uint(v.y); r[6] = __float_as_uint(v.z); r[7] = __float_as_uint(v.w);
-  r[8] = g;
+__device__ __forceinline__ void put_record(uint32_t* msg, uint32_t j, const float4 p, const float4 v, uint32_t g, const RecFmt f) {
+  uint32_t* r = msg + (size_t)j * f.words;
+  if (f.words == SPH_SLAB_COMPACT_WORDS) {
+    r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y); r[2] = __float_as_uint(p.z);
+    r[3] = __float_as_uint(v.x); r[4] = __float_as_uint(v.y); r[5] = __float_as_uint(v.z);
+    r[6] = g;
+  } else {
+    r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y); r[2] = __float_as_uint(p.z); r[3] = __float_as_uint(p.w);
+    r[4] = __float_as_uint(v.x); r[5] = __float_as_uint(v.y); r[6] = __float_as_uint(v.z); r[7] = __float_as_uint(v.w);
+    r[8] = g;
+  }
 }
+__device__ __forceinline__ uint32_t record_gid(const uint32_t* msg, int j, const RecFmt f) { return msg[(size_t)j * f.words + (f.words - 1)]; }
+__device__ __forceinline__ void get_record(const uint32_t* msg, int j, const RecFmt f, float4& p, float4& v) {
+  const uint32_t* r = msg + (size_t)j * f.words;
+  if (f.words == SPH_SLAB_COMPACT_WORDS) {
+    p = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(f.typeBits));
+    v = make_float4(__uint_as_float(r[3]), __uint_as_float(r[4]), __uint_as_float(r[5]), 0.f);
+  } else {
+    p = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+    v = make_float4(__uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]));
+  }
+}
+static RecFmt rec_fmt(const sph_solver* s) { return RecFmt{s->slabRecWords ? s->slabRecWords : SPH_SLAB_RECORD_WORDS, s->slabTypeBits}; }
 
 // Owned particles (flag set at the last rebuild) are the authoritative ones. All of them stay in the local set (they move
-// less than one cell layer per step); those now within W layers of a cut are also copied into the neighbour's message.
+// less than one cell layer per step); those now within W layers of a cut are also copied into the neighbour's message —
+// except boundary particles, which never move: every rank holds the boundary particles of its ghost layers from sph_slab_init
+// on and KEEPS them (a ghost that is a boundary particle goes to the kept set), so they are never sent again.
 // The compaction is ORDER-PRESERVING: the local arrays are sorted by global id, so the kept set and both messages come
 // out sorted by global id and the receiver can rebuild with a three-way merge instead of a sort. Three launches:
 //   k_slab_pack<false>  per workgroup of 2048 particles, how many go to each of the three destinations
@@ -33,7 +57,7 @@ template <bool WRITE>
 __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab, uint32_t* __restrict__ blockCounts,
                                                          const uint32_t* __restrict__ blockOffsets, uint32_t* __restrict__ msgDown,
                                                          uint32_t* __restrict__ msgUp, int capRecords, SlabPart part,
-                                                         uint32_t* __restrict__ moved) {
+                                                         uint32_t* __restrict__ moved, RecFmt fmt) {
   __shared__ uint32_t tot[PACK_ITEMS * (SPH_BLOCK / 64)][3];  // hits per (round, wave), then their exclusive prefix
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -55,16 +79,19 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab
         final_ = (sid >= a0 && sid < a1) || (sid >= b0 && sid < b1);
       }
       if (final_) {
-        const int layer = (int)(d.posOrig[i].z * d.cellSizeInv);  // the z cell coordinate hashParticles uses (sphFluid.cl:199)
+        const float4 pz = d.posOrig[i];
+        const int layer = (int)(pz.z * d.cellSizeInv);  // the z cell coordinate hashParticles uses (sphFluid.cl:199)
         // The 4-layer halo, the ranged stage launches and the overlapped tail all rest on "a particle moves less than one cell
         // layer per step": count the owned particles that did not (reported as SPH_ERR_INVALID by the host side of the pack).
         if (!WRITE && abs(layer - ((int)ownedAt - 1 + slab_base(slab))) > 1) atomicAdd(moved, 1u);
         if (part.mode != SLAB_PART_MESSAGES) f = 1u;
-        if (part.mode != SLAB_PART_KEPT) {
+        if (part.mode != SLAB_PART_KEPT && (int)pz.w != SPH_BOUNDARY_PARTICLE) {  // the boundary shell is static: never sent
           if (slab.hasLower && layer < slab.layerLo + slab.ghostLayers) f |= 2u;
           if (slab.hasUpper && layer >= slab.layerHi - slab.ghostLayers) f |= 4u;
         }
       }
+    } else if (i < d.N && part.mode != SLAB_PART_MESSAGES) {
+      if ((int)d.posOrig[i].w == SPH_BOUNDARY_PARTICLE) f = 1u;  // a boundary particle of the ghost layers: stays for good
     }
     flags[u] = f;
     uint32_t r = 0u;
@@ -98,15 +125,15 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_pack(SphDev d, sph_slab slab
       const uint32_t k = base0 + tot[g][0] + (rank[u] & 1023u);
       d.sortedPos[k] = p; d.sortedVel[k] = v; d.keys[k] = gid;  // sorted* / keys are free between two steps: staging area
     }
-    if (f & 2u) { const uint32_t j = base1 + tot[g][1] + ((rank[u] >> 10) & 1023u); if ((int)j < capRecords) put_record(msgDown, j, p, v, gid); }
-    if (f & 4u) { const uint32_t j = base2 + tot[g][2] + ((rank[u] >> 20) & 1023u); if ((int)j < capRecords) put_record(msgUp, j, p, v, gid); }
+    if (f & 2u) { const uint32_t j = base1 + tot[g][1] + ((rank[u] >> 10) & 1023u); if ((int)j < capRecords) put_record(msgDown, j, p, v, gid, fmt); }
+    if (f & 4u) { const uint32_t j = base2 + tot[g][2] + ((rank[u] >> 20) & 1023u); if ((int)j < capRecords) put_record(msgUp, j, p, v, gid, fmt); }
   }
 }
 
 // blockOffsets[b][c] = sum of blockCounts[b'][c] over b' < b; counts[c] = grand totals. One workgroup, 256 blocks per trip.
 __global__ __launch_bounds__(SPH_BLOCK) void k_slab_scan(const uint32_t* __restrict__ blockCounts, uint32_t* __restrict__ blockOffsets,
                                                          int nb, uint32_t* __restrict__ counts, uint32_t* __restrict__ headDown,
-                                                         uint32_t* __restrict__ headUp) {
+                                                         uint32_t* __restrict__ headUp, int recWords) {
   __shared__ uint32_t buf[SPH_BLOCK][3];
   __shared__ uint32_t carry[3];
   const int tid = threadIdx.x;
@@ -135,8 +162,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_scan(const uint32_t* __restr
   }
   if (tid < 3) counts[tid] = carry[tid];
   // framed messages ([payload words | payload | padding], sph_slab_pack_framed): the count word is written here, on the device
-  if (tid == 1 && headDown) *headDown = carry[1] * REC;
-  if (tid == 2 && headUp) *headUp = carry[2] * REC;
+  if (tid == 1 && headDown) *headDown = carry[1] * (uint32_t)recWords;
+  if (tid == 2 && headUp) *headUp = carry[2] * (uint32_t)recWords;
 }
 
 int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRecords, uint32_t* headDown, uint32_t* headUp,
@@ -145,9 +172,10 @@ int sphk_slab_pack(sph_solver* s, uint32_t* msgDown, uint32_t* msgUp, int capRec
   uint32_t* blockCounts = s->blockHist;  // the radix-sort workspace is idle between two steps: >= capacity/16 words
   uint32_t* blockOffsets = s->blockHist + (size_t)nb * 4;
   if (!counts) counts = s->slabCounts;
-  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part, s->slabCounts + 7);
-  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, counts, headDown, headUp);
-  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part, s->slabCounts + 7);
+  const RecFmt fmt = rec_fmt(s);
+  hipLaunchKernelGGL((k_slab_pack<false>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part, s->slabCounts + 7, fmt);
+  hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(SPH_BLOCK), 0, s->stream, blockCounts, blockOffsets, nb, counts, headDown, headUp, fmt.words);
+  hipLaunchKernelGGL((k_slab_pack<true>), dim3(nb), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, blockCounts, blockOffsets, msgDown, msgUp, capRecords, part, s->slabCounts + 7, fmt);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
@@ -173,14 +201,33 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_slab_gather(SphDev d, sph_slab sl
 // sorted by global id and global ids are unique, so the final index of an element is its own index plus the number of
 // smaller ids in the other two lists (two binary searches). A message that is not sorted raises slabCounts[3], which the
 // next sph_slab_pack reports as an error.
+// The three list lengths may live on the DEVICE (sph_slab_rebuild_framed): the kept count where the pack left it, the message
+// lengths in word 0 of the received frames — the host then enqueues the rebuild without knowing them and reads the totals back
+// once, afterwards (SlabIn::*Ptr non-null; the launch grids cover the capacities). A frame that claims more records than its
+// buffer holds, or a total beyond the solver's capacity, makes every merge kernel return at once and is reported by the totals.
+struct SlabIn {
+  const uint32_t* keptPtr; int keptHost;                        // kept count: *keptPtr if non-null
+  const uint32_t *down, *up;                                    // payloads (records)
+  const uint32_t *downWordsPtr, *upWordsPtr; int nDownHost, nUpHost;  // lengths: *wordsPtr / record words if non-null
+  int capDown, capUp, capacity;                                 // records the payload buffers hold; particles the solver holds
+};
+struct SlabCounts { int kept, nDown, nUp; bool ok; };
+__device__ __forceinline__ SlabCounts slab_counts(const SlabIn& in, const RecFmt f) {
+  SlabCounts c;
+  c.kept = in.keptPtr ? (int)*in.keptPtr : in.keptHost;
+  c.nDown = in.down ? (in.downWordsPtr ? (int)(*in.downWordsPtr / (uint32_t)f.words) : in.nDownHost) : 0;
+  c.nUp = in.up ? (in.upWordsPtr ? (int)(*in.upWordsPtr / (uint32_t)f.words) : in.nUpHost) : 0;
+  c.ok = c.nDown <= in.capDown && c.nUp <= in.capUp && (long long)c.kept + c.nDown + c.nUp <= (long long)in.capacity;
+  return c;
+}
 __device__ __forceinline__ int lower_bound_keys(const uint32_t* __restrict__ keys, int n, uint32_t g) {
   int lo = 0, hi = n;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < g) lo = mid + 1; else hi = mid; }
   return lo;
 }
-__device__ __forceinline__ int lower_bound_msg(const uint32_t* __restrict__ msg, int n, uint32_t g) {
+__device__ __forceinline__ int lower_bound_msg(const uint32_t* __restrict__ msg, int n, uint32_t g, const RecFmt f) {
   int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (msg[(size_t)mid * REC + 8] < g) lo = mid + 1; else hi = mid; }
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (record_gid(msg, mid, f) < g) lo = mid + 1; else hi = mid; }
   return lo;
 }
 __device__ __forceinline__ void place_particle(const SphDev& d, const sph_slab& slab, int at, const float4 p, const float4 v, uint32_t g) {
@@ -190,37 +237,59 @@ __device__ __forceinline__ void place_particle(const SphDev& d, const sph_slab& 
   d.owned[at] = owned_code(slab, (int)(p.z * d.cellSizeInv));
 }
 
-__global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_kept(SphDev d, sph_slab slab, int kept, const uint32_t* __restrict__ recvDown,
-                                                               int nDown, const uint32_t* __restrict__ recvUp, int nUp) {
+// totals: [0] kept, [1] records from below, [2] from above, [3] 0 = merged / 1 = nothing done (a frame or the capacity overflowed)
+__global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_kept(SphDev d, sph_slab slab, SlabIn in, RecFmt f, uint32_t* __restrict__ totals) {
+  const SlabCounts c = slab_counts(in, f);
   const int i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (i >= kept) return;
+  if (i == 0 && totals) { totals[0] = (uint32_t)c.kept; totals[1] = (uint32_t)c.nDown; totals[2] = (uint32_t)c.nUp; totals[3] = c.ok ? 0u : 1u; }
+  if (!c.ok || i >= c.kept) return;
   const uint32_t g = d.keys[i];
-  const int at = i + lower_bound_msg(recvDown, nDown, g) + lower_bound_msg(recvUp, nUp, g);
+  const int at = i + lower_bound_msg(in.down, c.nDown, g, f) + lower_bound_msg(in.up, c.nUp, g, f);
   place_particle(d, slab, at, d.sortedPos[i], d.sortedVel[i], g);
 }
 
-__global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_msg(SphDev d, sph_slab slab, int kept, const uint32_t* __restrict__ msg, int n,
-                                                              const uint32_t* __restrict__ other, int nOther, uint32_t* __restrict__ unsorted) {
+template <bool UP>
+__global__ __launch_bounds__(SPH_BLOCK) void k_slab_merge_msg(SphDev d, sph_slab slab, SlabIn in, RecFmt f, uint32_t* __restrict__ unsorted) {
+  const SlabCounts c = slab_counts(in, f);
   const int j = blockIdx.x * SPH_BLOCK + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t* r = msg + (size_t)j * REC;
-  const uint32_t g = r[8];
-  if (j > 0 && msg[(size_t)(j - 1) * REC + 8] >= g) atomicOr(unsorted, 1u);
-  const int at = j + lower_bound_keys(d.keys, kept, g) + lower_bound_msg(other, nOther, g);
-  place_particle(d, slab, at, make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])),
-                 make_float4(__uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7])), g);
+  const uint32_t* msg = UP ? in.up : in.down;
+  const uint32_t* other = UP ? in.down : in.up;
+  const int n = UP ? c.nUp : c.nDown, nOther = UP ? c.nDown : c.nUp;
+  if (!c.ok || j >= n) return;
+  const uint32_t g = record_gid(msg, j, f);
+  if (j > 0 && record_gid(msg, j - 1, f) >= g) atomicOr(unsorted, 1u);
+  const int at = j + lower_bound_keys(d.keys, c.kept, g) + lower_bound_msg(other, nOther, g, f);
+  float4 p, v;
+  get_record(msg, j, f, p, v);
+  place_particle(d, slab, at, p, v, g);
+}
+
+static int launch_merge(sph_solver* s, const SlabIn& in, int keptGrid, int downGrid, int upGrid, uint32_t* totals) {
+  const RecFmt fmt = rec_fmt(s);
+  { const int g = sph_guard_position_write(s); if (g != SPH_OK) return g; }
+  hipLaunchKernelGGL(k_slab_merge_kept, dim3(sph_blocks(keptGrid > 0 ? keptGrid : 1)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, in, fmt, totals);
+  if (in.down && downGrid > 0) hipLaunchKernelGGL((k_slab_merge_msg<false>), dim3(sph_blocks(downGrid)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, in, fmt, s->slabCounts + 3);
+  if (in.up && upGrid > 0) hipLaunchKernelGGL((k_slab_merge_msg<true>), dim3(sph_blocks(upGrid)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, in, fmt, s->slabCounts + 3);
+  SPH_HIP(hipGetLastError());
+  return SPH_OK;
 }
 
 int sphk_slab_rebuild(sph_solver* s, const uint32_t* recvDown, int nDown, const uint32_t* recvUp, int nUp, int kept) {
   const int total = kept + nDown + nUp;
-  { const int g = sph_guard_position_write(s); if (g != SPH_OK) return g; }
-  if (kept) hipLaunchKernelGGL(k_slab_merge_kept, dim3(sph_blocks(kept)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvDown, nDown, recvUp, nUp);
-  if (nDown) hipLaunchKernelGGL(k_slab_merge_msg, dim3(sph_blocks(nDown)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvDown, nDown, recvUp, nUp, s->slabCounts + 3);
-  if (nUp) hipLaunchKernelGGL(k_slab_merge_msg, dim3(sph_blocks(nUp)), dim3(SPH_BLOCK), 0, s->stream, s->d, s->slab, kept, recvUp, nUp, recvDown, nDown, s->slabCounts + 3);
-  SPH_HIP(hipGetLastError());
+  SlabIn in{nullptr, kept, nDown ? recvDown : nullptr, nUp ? recvUp : nullptr, nullptr, nullptr, nDown, nUp, nDown, nUp, s->capacity};
+  const int rc = launch_merge(s, in, kept, nDown, nUp, nullptr);
+  if (rc != SPH_OK) return rc;
   s->d.N = total;
   s->progress = 0;
   return SPH_OK;
+}
+
+// The same with every length on the device: frames are [payload words | payload]; the kept count is at keptPtr. s->d.N is NOT
+// updated here (the host does not know the total yet): sph_api.hip reads `totals` back and finishes the rebuild.
+int sphk_slab_rebuild_framed(sph_solver* s, const uint32_t* frameDown, int capDown, const uint32_t* frameUp, int capUp,
+                             const uint32_t* keptPtr, uint32_t* totals) {
+  SlabIn in{keptPtr, 0, frameDown ? frameDown + 1 : nullptr, frameUp ? frameUp + 1 : nullptr, frameDown, frameUp, 0, 0, capDown, capUp, s->capacity};
+  return launch_merge(s, in, s->d.N, capDown, capUp, totals);  // (the kept set is a subset of the current local set)
 }
 
 // Initial set in any order (sph_slab_init): staging area holds n records; sort them by global id.

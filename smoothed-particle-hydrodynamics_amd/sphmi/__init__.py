@@ -41,6 +41,7 @@ class SphSlab(C.Structure):
 
 
 SLAB_RECORD_WORDS = 9
+SLAB_COMPACT_WORDS = 7  # x, y, z, vx, vy, vz, global id (sph_slab_set_record_format)
 
 
 class SphError(RuntimeError):
@@ -96,7 +97,8 @@ EXPORTED_SYMBOLS = ["sph_create", "sph_destroy", "sph_run_pcisph_integrate", "sp
                     "sph_read_position_async", "sph_read_position_wait", "sph_host_unregister", "sph_build_info",
                     "sph_read_buffer", "sph_read_neighbor_rows", "sph_synchronize", "sph_set_stage_timing", "sph_get_stage_times",
                     "sph_reset_stage_times", "sph_step_sort_passes", "sph_last_error", "sph_abi_version", "sph_slab_init", "sph_slab_pack", "sph_slab_pack_framed", "sph_slab_step_begin", "sph_slab_step_messages",
-                    "sph_slab_rebuild", "sph_particle_count", "sph_slab_read"] + _STAGE_FUNCS
+                    "sph_slab_rebuild", "sph_particle_count", "sph_slab_read", "sph_slab_rebuild_framed", "sph_slab_rebuild_finish",
+                    "sph_slab_liquid_signature", "sph_slab_set_record_format", "sph_stream_wait_event"] + _STAGE_FUNCS
 HOST_EXPORTED_SYMBOLS = ["sphmi_default_config", "sphmi_config_set_box", "sphmi_count_particles",
                          "sphmi_load_configuration", "sphmi_load_elastic_connections", "sphmi_box_counts",
                          "sphmi_generate_box", "sphmi_box_layer_histogram", "sphmi_generate_box_slice", "sphmi_muscle_signal", "sphmi_save_configuration", "sphmi_worm_counts",
@@ -166,6 +168,11 @@ def device_lib():
         L.sph_slab_step_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32]
         L.sph_slab_step_messages.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.sph_slab_rebuild.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.sph_slab_rebuild_framed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.sph_slab_rebuild_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.sph_slab_liquid_signature.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.sph_slab_set_record_format.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
+        L.sph_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
         L.sph_particle_count.argtypes = [C.c_void_p]
         L.sph_slab_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _dev = L
@@ -506,6 +513,29 @@ class owHIPSolver:
         self._chk(self._L.sph_slab_rebuild(self._h, recv_down_ptr, n_down, recv_up_ptr, n_up))
         self.N = self._L.sph_particle_count(self._h)
         return self.N
+
+    def slab_rebuild_framed(self, frame_down_ptr, cap_down_records, frame_up_ptr, cap_up_records):
+        """Asynchronous rebuild from complete received frames; the new count arrives with slab_rebuild_finish()."""
+        self._chk(self._L.sph_slab_rebuild_framed(self._h, frame_down_ptr, cap_down_records, frame_up_ptr, cap_up_records))
+
+    def slab_rebuild_finish(self):
+        """(kept, records from below, records from above, nothing_merged) of the last slab_rebuild_framed; blocks."""
+        c = (C.c_int32 * 4)()
+        self._chk(self._L.sph_slab_rebuild_finish(self._h, c))
+        if not c[3]:
+            self.N = self._L.sph_particle_count(self._h)
+        return c[0], c[1], c[2], bool(c[3])
+
+    def slab_liquid_signature(self):
+        b = C.c_uint32()
+        self._chk(self._L.sph_slab_liquid_signature(self._h, C.byref(b)))
+        return b.value
+
+    def slab_set_record_format(self, words, type_bits=0):
+        return self._chk(self._L.sph_slab_set_record_format(self._h, words, type_bits))
+
+    def stream_wait_event(self, hip_event_handle):
+        return self._chk(self._L.sph_stream_wait_event(self._h, C.c_void_p(hip_event_handle)))
 
     def slab_read(self):
         n = self._L.sph_particle_count(self._h)

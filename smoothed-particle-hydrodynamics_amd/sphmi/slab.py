@@ -12,17 +12,33 @@ Particles owned at the last rebuild therefore see exactly the inputs a single-GP
 local arrays are kept sorted by global id the within-cell order is the global one: owned results are bit-identical to
 the single-solver run (tests/test_slab.py).
 
+Boundary particles never move, so every rank keeps the boundary particles of its ghost layers from the start and the
+messages carry the other particles only; when all ranks find one common type word and velocity.w == 0 on those (always the
+case for generated scenes) a record shrinks from 9 to 7 words (28 B: x, y, z, vx, vy, vz, global id).
+
 The numerical work sits behind a tiny backend interface so that the exchange logic itself can be tested on CPU:
   backend.count                         current local particle count
+  backend.record_words                  words per message record (9, or 7 once set_record_format(7, type_bits) was called)
+  backend.liquid_signature()            common type word of the local non-boundary particles (0 none, 0xffffffff not uniform)
   backend.step(iteration)               advance every local particle one step
-  backend.pack() -> (kept, msg_down, msg_up)   int32 tensors of 9 words per record (position, velocity, global id)
-  backend.rebuild(recv_down, recv_up)   new local set = kept + received, sorted by global id
+  backend.pack() -> (kept, msg_down, msg_up)   int32 tensors of record_words words per record
+  backend.rebuild(recv_down, recv_up)   new local set = kept (owned particles + the static boundary ghosts) + received,
+                                        sorted by global id
+
+Under RCCL with the HIP backend a step costs the host ONE wait (for the packed frames): the frames are sent in place, the solver's
+stream waits for the receive through an event, the rebuild kernels take the received counts from the frames on the device
+(sph_slab_rebuild_framed), and the new particle count is collected at the start of the next step.
 """
 import ctypes as C
 
 import numpy as np
 
-from . import SLAB_RECORD_WORDS, SphSlab, owHIPSolver
+from . import SLAB_COMPACT_WORDS, SLAB_RECORD_WORDS, SphSlab, owHIPSolver
+
+def os_environ_flag(name):
+    import os
+    return os.environ.get(name, "0") not in ("", "0")
+
 
 GHOST_LAYERS = 4
 OPEN_LO, OPEN_HI = -(1 << 30), (1 << 30)  # the first / last slab own everything below / above
@@ -126,11 +142,19 @@ class HipSlabBackend:
         self.solver = owHIPSolver(cfg, position, velocity)
         self.solver.slab_init(slab, global_ids)
         self.cap_records = cfg.capacity // 2
+        self.record_words = SLAB_RECORD_WORDS
         dev = torch.device("cuda", cfg.device)
         # message frames: [payload word count | records ...]; libsphmi writes both parts on the device (sph_slab_pack_framed)
         self.frame_down = torch.empty(1 + self.cap_records * SLAB_RECORD_WORDS, dtype=torch.int32, device=dev)
         self.frame_up = torch.empty_like(self.frame_down)
         self.device = self.frame_device = dev
+
+    def liquid_signature(self):
+        return self.solver.slab_liquid_signature()
+
+    def set_record_format(self, words, type_bits=0):
+        self.solver.slab_set_record_format(words, type_bits)
+        self.record_words = words
 
     @property
     def count(self):
@@ -145,13 +169,13 @@ class HipSlabBackend:
         self.solver.slab_step_begin(iteration, C.c_void_p(self.frame_down.data_ptr()), C.c_void_p(self.frame_up.data_ptr()),
                                     self.cap_records)
         nd, nu = self.solver.slab_step_messages()
-        return None, self.frame_down, nd * SLAB_RECORD_WORDS, self.frame_up, nu * SLAB_RECORD_WORDS
+        return None, self.frame_down, nd * self.record_words, self.frame_up, nu * self.record_words
 
     def pack_framed(self):
         """(kept, frame_down, payload words, frame_up, payload words): frames ready to be sent from word 0."""
         kept, nd, nu = self.solver.slab_pack_framed(C.c_void_p(self.frame_down.data_ptr()), C.c_void_p(self.frame_up.data_ptr()),
                                                     self.cap_records)
-        return kept, self.frame_down, nd * SLAB_RECORD_WORDS, self.frame_up, nu * SLAB_RECORD_WORDS
+        return kept, self.frame_down, nd * self.record_words, self.frame_up, nu * self.record_words
 
     def pack(self):
         kept, fd, nd, fu, nu = self.pack_framed()
@@ -165,12 +189,40 @@ class HipSlabBackend:
                 return None, 0
             t = t.to(self.device).contiguous()
             keep.append(t)
-            return C.c_void_p(t.data_ptr()), t.numel() // SLAB_RECORD_WORDS
+            return C.c_void_p(t.data_ptr()), t.numel() // self.record_words
         pd, nd = ptr_n(recv_down)
         pu, nu = ptr_n(recv_up)
         n = self.solver.slab_rebuild(pd, nd, pu, nu)
         self._keep = keep
         return n
+
+    def rebuild_framed(self, frame_down, frame_up):
+        """Asynchronous rebuild from complete frames [payload words | payload] (None where there is no neighbour); every count is
+        read on the device. rebuild_finish() collects the result."""
+        keep = []
+
+        def ptr_cap(t):
+            if t is None:
+                return None, 0
+            t = t.to(self.device).contiguous()
+            keep.append(t)
+            return C.c_void_p(t.data_ptr()), (t.numel() - 1) // self.record_words
+        pd, cd = ptr_cap(frame_down)
+        pu, cu = ptr_cap(frame_up)
+        self.solver.slab_rebuild_framed(pd, cd, pu, cu)
+        self._keep = keep
+
+    def rebuild_finish(self):
+        """(kept, records from below, from above, nothing_merged): nothing_merged means a frame was shorter than its message —
+        fetch the rest and call rebuild() with the complete payloads."""
+        return self.solver.slab_rebuild_finish()
+
+    def wait_for(self, stream):
+        """The solver's stream waits (on the device) for everything enqueued so far on the torch stream `stream`."""
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        self.solver.stream_wait_event(ev.cuda_event)
+        self._keep_event = ev
 
     def owned_state(self):
         pos, vel, gid, owned = self.solver.slab_read()
@@ -181,7 +233,7 @@ class HipSlabBackend:
 class SlabDecomposition:
     """Drives one backend per rank: step, then the halo exchange with the two neighbouring ranks."""
 
-    def __init__(self, backend, rank, world, dist=None, comm_device=None):
+    def __init__(self, backend, rank, world, dist=None, comm_device=None, record_format="auto"):
         import torch
         self.torch = torch
         self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
@@ -196,6 +248,34 @@ class SlabDecomposition:
         # overlap the exchange with the tail of the step (sph_slab_step_begin); SPHMI_SLAB_OVERLAP=0 restores step-then-pack
         import os
         self.overlap = os.environ.get("SPHMI_SLAB_OVERLAP", "1") != "0"
+        self._pending = None        # asynchronous exchange in flight (RCCL path): collected by finish()
+        if record_format == "auto":
+            record_format = self._agree_on_record_format()
+        if record_format is not None and hasattr(backend, "set_record_format"):
+            backend.set_record_format(*record_format)
+
+    @property
+    def rec(self):
+        return getattr(self.backend, "record_words", SLAB_RECORD_WORDS)
+
+    def _agree_on_record_format(self):
+        """Compact 7-word records if every rank's non-boundary particles carry the same type word and velocity.w == 0 (the
+        solvers checked their own particles when they were created; one all-gather of a word settles it for the run)."""
+        if not hasattr(self.backend, "liquid_signature") or os_environ_flag("SPHMI_SLAB_FULL_RECORDS"):
+            return None
+        mine = int(self.backend.liquid_signature())
+        sigs = [mine]
+        if self.dist is not None and self.world > 1:
+            if not hasattr(self.dist, "all_gather"):
+                return None
+            t = self.torch.tensor([mine], dtype=self.torch.int64, device=self.comm_device)
+            out = [self.torch.zeros_like(t) for _ in range(self.world)]
+            self.dist.all_gather(out, t)
+            sigs = [int(o.item()) for o in out]
+        real = {v for v in sigs if v != 0}
+        if 0xffffffff in real or len(real) != 1:
+            return None
+        return SLAB_COMPACT_WORDS, real.pop()
 
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
@@ -206,10 +286,16 @@ class SlabDecomposition:
     # the very first exchange, and a payload that outgrows its bound (the count word says so), use an explicit second
     # transfer of exactly the missing words.
     @staticmethod
-    def next_bound(words):
-        rec = words // SLAB_RECORD_WORDS
+    def next_bound(words, record_words=SLAB_RECORD_WORDS):
+        rec = words // record_words
         rec = rec + rec // 8 + 1024
-        return ((rec + 255) // 256) * 256 * SLAB_RECORD_WORDS
+        return ((rec + 255) // 256) * 256 * record_words
+
+    def _next_bound(self, words):
+        try:
+            return self.next_bound(words, self.rec)
+        except TypeError:  # (tests replace next_bound by a one-argument function)
+            return self.next_bound(words)
 
     def _frame(self, key, words):
         """A reusable int32 buffer of 1 + words entries on the communication device."""
@@ -293,13 +379,92 @@ class SlabDecomposition:
                 recv[p] = inn[p][1:1 + n_in[p]]
         self._transfer(sends, recvs)
         for p in peers:
-            self._bound_out[p] = self.next_bound(n_out[p])
-            self._bound_in[p] = self.next_bound(n_in[p])
+            self._bound_out[p] = self._next_bound(n_out[p])
+            self._bound_in[p] = self._next_bound(n_in[p])
         self.transfers += 1 + (1 if (sends or recvs) else 0)
+        if hasattr(self.backend, "rebuild_framed") and not (sends or recvs) and all(1 + n_in[p] <= inn[p].numel() for p in peers):
+            # the received frames are complete: let the backend read the counts from the frames on the device, as the RCCL path does
+            self.backend.rebuild_framed(inn.get(self.lower), inn.get(self.upper))
+            kept, n_down, n_up, nothing = self.backend.rebuild_finish()
+            assert not nothing and n_down * self.rec == n_in.get(self.lower, 0) and n_up * self.rec == n_in.get(self.upper, 0)
+            return self.backend.count
         return self.backend.rebuild(recv.get(self.lower), recv.get(self.upper))
+
+    # ---- RCCL path: one host wait per step. The frames the backend packed on the device are sent in place; the solver's stream
+    # waits for the receive through an event; the rebuild reads the received counts on the device; the new local count (and
+    # whether a message outgrew its agreed frame) is collected by finish() at the start of the next step.
+    def _can_run_async(self):
+        return (self.overlap and self.world > 1 and self.comm_device.type == "cuda" and hasattr(self.backend, "rebuild_framed")
+                and hasattr(self.backend, "step_and_pack_framed") and getattr(self.backend, "frame_device", None) == self.comm_device
+                and not os_environ_flag("SPHMI_SLAB_SYNC_EXCHANGE"))
+
+    def _exchange_async(self, prepacked):
+        torch, dist = self.torch, self.dist
+        _, frame_down, nd, frame_up, nu = prepacked
+        frames = {self.lower: frame_down, self.upper: frame_up}
+        n_out = {self.lower: nd, self.upper: nu}
+        peers = [p for p in (self.lower, self.upper) if p is not None]
+        if not self._bound_out:  # first exchange: the frames carry the count word only; finish() fetches the payloads
+            for p in peers:
+                self._bound_out[p] = self._bound_in[p] = 0
+        out, inn = {}, {}
+        for p in peers:
+            b = min(self._bound_out[p], frames[p].numel() - 1)
+            self._bound_out[p] = b
+            out[p] = frames[p][:1 + b]
+            inn[p] = self._frame(("in", p), self._bound_in[p])
+        ops = [dist.P2POp(dist.isend, out[p], p) for p in peers] + [dist.P2POp(dist.irecv, inn[p], p) for p in peers]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()  # torch's current stream waits for RCCL — the host does not
+        self.backend.wait_for(torch.cuda.current_stream(self.comm_device))  # ... and the solver's stream waits for that
+        self.backend.rebuild_framed(inn.get(self.lower), inn.get(self.upper))
+        self.bytes_sent += sum(4 * out[p].numel() for p in peers)
+        self.transfers += 1
+        self._pending = dict(frames=frames, n_out={p: n_out[p] for p in peers}, inn=inn, peers=peers)
+
+    def finish(self):
+        """Collect the asynchronous exchange of the last step (no-op otherwise): the new local count, the next frame lengths,
+        and — rare — the part of a message that did not fit its agreed frame. Returns the local particle count."""
+        pend, self._pending = self._pending, None
+        if pend is None:
+            return self.backend.count
+        torch = self.torch
+        kept, n_down, n_up, nothing = self.backend.rebuild_finish()
+        peers, frames, inn, n_out = pend["peers"], pend["frames"], pend["inn"], pend["n_out"]
+        n_in = {self.lower: n_down * self.rec, self.upper: n_up * self.rec}
+        sends, recvs, recv = [], [], {}
+        for p in peers:
+            b_out, b_in = self._bound_out[p], self._bound_in[p]
+            if n_out[p] > b_out:  # both ends of a link see the same two numbers, so both take part in the second transfer
+                rest = frames[p][1 + b_out:1 + n_out[p]]
+                sends.append((rest, p))
+                self.bytes_sent += 4 * rest.numel()
+            if n_in[p] > b_in:
+                full = torch.empty(n_in[p], dtype=torch.int32, device=self.comm_device)
+                if b_in:
+                    full[:b_in] = inn[p][1:1 + b_in]
+                recvs.append((full[b_in:], p))
+                recv[p] = full
+            else:
+                recv[p] = inn[p][1:1 + n_in[p]]
+        if sends or recvs:
+            self._transfer(sends, recvs)
+            self.transfers += 1
+        if nothing:  # a received frame was shorter than its message: rebuild from the complete payloads
+            self.backend.rebuild(recv.get(self.lower), recv.get(self.upper))
+        for p in peers:
+            self._bound_out[p] = self._next_bound(n_out[p])
+            self._bound_in[p] = self._next_bound(n_in[p])
+        return self.backend.count
 
     def step(self, iteration):
         import time
+        if self._can_run_async():
+            t0 = time.perf_counter()  # (includes the wait for the step itself up to the packed messages)
+            self.finish()
+            self._exchange_async(self.backend.step_and_pack_framed(iteration))
+            self.exchange_seconds = getattr(self, "exchange_seconds", 0.0) + time.perf_counter() - t0
+            return None  # the count arrives with finish()
         if self.overlap and self.world > 1 and hasattr(self.backend, "step_and_pack_framed"):
             t0 = time.perf_counter()  # (includes the wait for the step itself up to the packed messages)
             n = self.exchange(self.backend.step_and_pack_framed(iteration))

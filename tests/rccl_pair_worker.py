@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import scenes  # noqa: E402,F401
 import slab_worker  # noqa: E402
+import sphmi  # noqa: E402
 from sphmi import slab as S  # noqa: E402
 
 
@@ -73,6 +74,9 @@ def main():
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % a.port, rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     paired = PairedDist(dist)
+    if os.environ.get("SPHMI_TEST_BOUND_WORDS"):  # force the "payload outgrew its frame" path: tiny agreed bounds
+        words = int(os.environ["SPHMI_TEST_BOUND_WORDS"])
+        S.SlabDecomposition.next_bound = staticmethod(lambda n: words)
     sc = slab_worker.scene()
     n_global = sc["cfg"].particleCount
     layers = S.particle_layers(sc["position"], sc["cfg"])
@@ -84,7 +88,12 @@ def main():
         slab = S.make_slab(cuts, rank, 2, n_global)
         idx = S.local_indices(layers, slab)
         backend = S.HipSlabBackend(cfg, sc["position"][idx], sc["velocity"][idx], idx, slab)
-        decs.append(S.SlabDecomposition(backend, rank, 2, paired))
+        decs.append(S.SlabDecomposition(backend, rank, 2, paired, record_format=None))
+    # (the in-process stand-in has no all_gather: agree on the record format by hand, as SlabDecomposition does across ranks)
+    sigs = {d.backend.liquid_signature() for d in decs} - {0}
+    if len(sigs) == 1 and 0xffffffff not in sigs and not os.environ.get("SPHMI_SLAB_FULL_RECORDS"):
+        for d in decs:
+            d.backend.set_record_format(sphmi.SLAB_COMPACT_WORDS, next(iter(sigs)))
     assert all(d.comm_device.type == "cuda" for d in decs)
     errors = []
 
@@ -94,6 +103,7 @@ def main():
             paired.local.rank = rank
             for it in range(a.steps):
                 decs[rank].step(it)
+            decs[rank].finish()
         except BaseException as e:  # surface worker failures in the parent instead of hanging the barrier
             errors.append(e)
             paired.barrier.abort()
@@ -108,7 +118,8 @@ def main():
     for rank in (0, 1):
         gid, p, v = decs[rank].backend.owned_state()
         np.savez(os.path.join(a.out, "rank%d.npz" % rank), gid=gid, pos=p, vel=v, counts=np.array([decs[rank].backend.count]),
-                 cuts=np.array(cuts), sent=decs[rank].bytes_sent, transfers=decs[rank].transfers)
+                 cuts=np.array(cuts), sent=decs[rank].bytes_sent, transfers=decs[rank].transfers, record_words=decs[rank].rec,
+                 asynchronous=decs[rank]._can_run_async())
     print("rccl groups issued:", paired.groups)
     dist.destroy_process_group()
 

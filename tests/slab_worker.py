@@ -19,6 +19,7 @@ import sphmi  # noqa: E402
 from sphmi import slab as S  # noqa: E402
 
 REC = sphmi.SLAB_RECORD_WORDS
+BOUNDARY = sphmi.BOUNDARY_PARTICLE
 
 
 def scene():
@@ -29,6 +30,8 @@ def scene():
         rng = np.random.default_rng(int(os.environ["SPHMI_TEST_FUZZ_SEED"]) + 7)
         nl = sc["numOfLiquidP"]
         sc["velocity"][:nl, :3] = rng.uniform(-1.0, 1.0, size=(nl, 3)).astype(np.float32)
+    if os.environ.get("SPHMI_TEST_ODD_W"):  # one liquid particle with velocity.w != 0: compact 7-word records would lose it
+        sc["velocity"][5, 3] = np.float32(0.25)
     if os.environ.get("SPHMI_TEST_VZ"):  # the liquid drifts along z (across the cuts): ownership must change hands during the run
         nl = sc["numOfLiquidP"]
         sc["velocity"][:nl, 2] = np.float32(os.environ["SPHMI_TEST_VZ"])
@@ -79,17 +82,35 @@ class OracleSlabBackend:
         self.vel = o.buffer("velocity").reshape(-1, 4)[:self.count].copy()
         o.close()
 
+    # ---- the record formats of include/sphmi.h: 9 words, or 7 (x, y, z, vx, vy, vz, gid) with the type word as a constant
+    record_words = REC
+
+    def liquid_signature(self):
+        nb = self.pos[:, 3].astype(np.int32) != BOUNDARY
+        if not nb.any():
+            return 0
+        t = np.unique(self.pos[nb, 3].view(np.uint32))
+        if t.size != 1 or np.any(self.vel[nb, 3].view(np.uint32) != 0):
+            return 0xffffffff
+        return int(t[0])
+
+    def set_record_format(self, words, type_bits=0):
+        self.record_words, self.type_bits = words, np.uint32(type_bits)
+
     def _records(self, m):
-        rec = np.concatenate([self.pos[m].view(np.int32), self.vel[m].view(np.int32), self.gid[m].view(np.int32)[:, None]], axis=1)
+        p, v, g = self.pos[m].view(np.int32), self.vel[m].view(np.int32), self.gid[m].view(np.int32)[:, None]
+        rec = np.concatenate([p, v, g], axis=1) if self.record_words == REC else np.concatenate([p[:, :3], v[:, :3], g], axis=1)
         return self.torch.from_numpy(np.ascontiguousarray(rec).reshape(-1))
 
     def pack(self):
         lay = S.particle_layers(self.pos, self.cfg)
         a = self.owned
-        down = a & (lay < self.slab.layerLo + self.slab.ghostLayers) & bool(self.slab.hasLower)
-        up = a & (lay >= self.slab.layerHi - self.slab.ghostLayers) & bool(self.slab.hasUpper)
-        self._kept = (self.pos[a], self.vel[a], self.gid[a])
-        return int(a.sum()), self._records(down), self._records(up)
+        liquid = self.pos[:, 3].astype(np.int32) != BOUNDARY   # the boundary shell is static: kept by every rank, never sent
+        down = a & liquid & (lay < self.slab.layerLo + self.slab.ghostLayers) & bool(self.slab.hasLower)
+        up = a & liquid & (lay >= self.slab.layerHi - self.slab.ghostLayers) & bool(self.slab.hasUpper)
+        keep = a | ~liquid
+        self._kept = (self.pos[keep], self.vel[keep], self.gid[keep])
+        return int(keep.sum()), self._records(down), self._records(up)
 
     def pack_framed(self):
         """[payload word count | payload] frames on the CPU, like HipSlabBackend's in HBM (exercises the zero-copy path)."""
@@ -104,10 +125,17 @@ class OracleSlabBackend:
 
     def rebuild(self, recv_down, recv_up):
         parts = [self._kept]
+        W = self.record_words
         for t in (recv_down, recv_up):
             if t is not None and t.numel():
-                r = t.cpu().numpy().reshape(-1, REC)
-                parts.append((r[:, 0:4].view(np.float32), r[:, 4:8].view(np.float32), r[:, 8].view(np.uint32)))
+                r = t.cpu().numpy().reshape(-1, W)
+                if W == REC:
+                    parts.append((r[:, 0:4].view(np.float32), r[:, 4:8].view(np.float32), r[:, 8].view(np.uint32)))
+                else:
+                    n = r.shape[0]
+                    p = np.concatenate([r[:, 0:3], np.full((n, 1), self.type_bits, np.uint32).view(np.int32)], axis=1)
+                    v = np.concatenate([r[:, 3:6], np.zeros((n, 1), np.int32)], axis=1)
+                    parts.append((np.ascontiguousarray(p).view(np.float32), np.ascontiguousarray(v).view(np.float32), r[:, 6].view(np.uint32)))
         pos = np.concatenate([p[0] for p in parts]); vel = np.concatenate([p[1] for p in parts]); gid = np.concatenate([p[2] for p in parts])
         order = np.argsort(gid, kind="stable")
         assert np.unique(gid).size == gid.size, "duplicate particle after the halo exchange"
@@ -151,10 +179,11 @@ def main():
     counts = []
     for it in range(a.steps):
         counts.append(dd.step(it))
+    dd.finish()
     gid, p, v = backend.owned_state()
     first_owner = np.searchsorted(np.array(cuts[1:-1]), layers, side="right")  # rank that owned each particle at the start
     np.savez(os.path.join(a.out, "rank%d.npz" % a.rank), gid=gid, pos=p, vel=v, counts=np.array(counts),
-             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers,
+             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers, record_words=dd.rec,
              adopted=int((first_owner[gid.astype(np.int64)] != a.rank).sum()))  # owned now, owned by another rank at the start
     dist.barrier()
     dist.destroy_process_group()

@@ -109,6 +109,22 @@ def test_two_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
     check_union(results, sc, pos_ref, vel_ref)
     # framing: the first exchange needs a second transfer (no agreed bound yet), every later step exactly one
     assert all(int(r["transfers"]) == STEPS + 1 for r in results)
+    assert all(int(r["record_words"]) == sphmi.SLAB_COMPACT_WORDS for r in results)  # generated scene: one type word, velocity.w = 0
+
+
+def test_record_formats_cpu(tmp_path):
+    """Full 9-word records on request, and automatically when one non-boundary particle has velocity.w != 0 (every rank must
+    agree: the odd particle lives on one rank only). Same bits as the single domain either way; compact records send fewer bytes."""
+    sc, pos_ref, vel_ref = single_domain_reference()
+    compact = run_ranks("oracle", 2, tmp_path)
+    full = run_ranks("oracle", 2, tmp_path, env={"SPHMI_SLAB_FULL_RECORDS": "1"})
+    check_union(full, sc, pos_ref, vel_ref)
+    assert all(int(r["record_words"]) == sphmi.SLAB_RECORD_WORDS for r in full)
+    assert all(int(c["sent"]) < int(f["sent"]) for c, f in zip(compact, full))
+    odd = run_ranks("oracle", 2, tmp_path, env={"SPHMI_TEST_ODD_W": "1"})
+    sc, pos_ref, vel_ref = single_domain_reference(env={"SPHMI_TEST_ODD_W": "1"})
+    check_union(odd, sc, pos_ref, vel_ref)
+    assert all(int(r["record_words"]) == sphmi.SLAB_RECORD_WORDS for r in odd)
 
 
 def test_backend_owned_frames_are_sent_in_place_cpu(tmp_path):
@@ -273,6 +289,27 @@ def test_two_slabs_exchange_frames_over_rccl_in_one_process(tmp_path):
     sc, pos_ref, vel_ref = single_domain_reference(steps=steps)
     check_union(results, sc, pos_ref, vel_ref)
     assert all(int(x["transfers"]) == steps + 1 for x in results)   # one framed transfer per step after the first exchange
+    assert all(bool(x["asynchronous"]) and int(x["record_words"]) == sphmi.SLAB_COMPACT_WORDS for x in results)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SPHMI_TEST_BOUND_WORDS": "36"}, {"SPHMI_SLAB_FULL_RECORDS": "1"},
+                                 {"SPHMI_SLAB_SYNC_EXCHANGE": "1"}, dict(DRIFT, SPHMI_TEST_LONG_SCENE="1")])
+def test_rccl_exchange_variants_in_one_process(tmp_path, env):
+    """The asynchronous RCCL exchange (counts read on the device, one host wait per step) with frames too short for their
+    messages in EVERY step (the rest is fetched by finish() and the rebuild repeated from the complete payloads), with full 9-word
+    records, against the synchronous exchange, and with liquid drifting across the cut."""
+    steps = 5
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_pair_worker.py"), "--steps", str(steps), "--port", str(free_port()),
+                        "--out", str(tmp_path)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    results = [np.load(os.path.join(tmp_path, "rank%d.npz" % k)) for k in range(2)]
+    ref_env = {k: v for k, v in env.items() if k.startswith("SPHMI_TEST_") and k != "SPHMI_TEST_BOUND_WORDS"}
+    sc, pos_ref, vel_ref = single_domain_reference(steps=steps, long_scene="SPHMI_TEST_LONG_SCENE" in env, env=ref_env)
+    check_union(results, sc, pos_ref, vel_ref)
+    if "SPHMI_TEST_BOUND_WORDS" in env:
+        assert all(int(x["transfers"]) == 2 * steps for x in results)
+    assert all(bool(x["asynchronous"]) == ("SPHMI_SLAB_SYNC_EXCHANGE" not in env) for x in results)
 
 
 @pytest.mark.gpu
