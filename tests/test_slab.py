@@ -116,12 +116,15 @@ def test_record_formats_cpu(tmp_path):
     """Full 9-word records on request, and automatically when one non-boundary particle has velocity.w != 0 (every rank must
     agree: the odd particle lives on one rank only). Same bits as the single domain either way; compact records send fewer bytes."""
     sc, pos_ref, vel_ref = single_domain_reference()
-    compact = run_ranks("oracle", 2, tmp_path)
-    full = run_ranks("oracle", 2, tmp_path, env={"SPHMI_SLAB_FULL_RECORDS": "1"})
+    dirs = [tmp_path / name for name in ("compact", "full", "odd")]  # (np.load is lazy: every run keeps its own files)
+    for d in dirs:
+        d.mkdir()
+    compact = run_ranks("oracle", 2, dirs[0])
+    full = run_ranks("oracle", 2, dirs[1], env={"SPHMI_SLAB_FULL_RECORDS": "1"})
     check_union(full, sc, pos_ref, vel_ref)
     assert all(int(r["record_words"]) == sphmi.SLAB_RECORD_WORDS for r in full)
     assert all(int(c["sent"]) < int(f["sent"]) for c, f in zip(compact, full))
-    odd = run_ranks("oracle", 2, tmp_path, env={"SPHMI_TEST_ODD_W": "1"})
+    odd = run_ranks("oracle", 2, dirs[2], env={"SPHMI_TEST_ODD_W": "1"})
     sc, pos_ref, vel_ref = single_domain_reference(env={"SPHMI_TEST_ODD_W": "1"})
     check_union(odd, sc, pos_ref, vel_ref)
     assert all(int(r["record_words"]) == sphmi.SLAB_RECORD_WORDS for r in odd)
