@@ -359,12 +359,15 @@ def test_initial_ids_in_any_order_and_unsorted_message_is_rejected():
     assert down.numel() == 0 and up.numel() > 0
     rec = up.cpu().numpy().view(np.uint32).reshape(-1, S.SLAB_RECORD_WORDS if hasattr(S, "SLAB_RECORD_WORDS") else 9)
     assert np.all(np.diff(rec[:, 8].astype(np.int64)) > 0)            # messages leave sorted by global id
-    # a well-formed message from "above": the ghost particles this rank would receive = its own non-owned ones, sorted
-    ghosts = np.flatnonzero(owned == 0)
+    assert not np.any(rec[:, 3].view(np.float32).astype(np.int32) == sphmi.BOUNDARY_PARTICLE)  # the static shell is never sent
+    # a well-formed message from "above": what this rank would receive = its own ghosts minus the boundary ones, which it keeps
+    is_bnd = pos[:, 3].astype(np.int32) == sphmi.BOUNDARY_PARTICLE
+    ghosts = np.flatnonzero((owned == 0) & ~is_bnd)
+    assert kept == int(((owned != 0) | is_bnd).sum())                    # kept = owned + the boundary particles of the ghost layers
     msg = np.zeros((ghosts.size, 9), np.uint32)
     msg[:, 0:4] = pos[ghosts].view(np.uint32); msg[:, 4:8] = vel[ghosts].view(np.uint32); msg[:, 8] = gid[ghosts]
     good = torch.from_numpy(msg.view(np.int32).reshape(-1)).to(be.device)
-    assert be.rebuild(None, good) == kept + ghosts.size
+    assert be.rebuild(None, good) == kept + ghosts.size == idx.size
     _, _, gid2, _ = be.solver.slab_read()
     assert np.all(np.diff(gid2.astype(np.int64)) > 0)                  # merged set is sorted
     be.step(1)

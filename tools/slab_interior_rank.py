@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 import scenes
-from sphmi import slab as S, SLAB_RECORD_WORDS as REC
+from sphmi import slab as S
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 delay = float(sys.argv[2]) * 1e-6 if len(sys.argv) > 2 else 150e-6
@@ -31,7 +31,15 @@ for r in range(world):
     slab = S.make_slab(cuts, r, world, n_global)
     idx = S.local_indices(layers, slab)
     backs.append(S.HipSlabBackend(cfg, sc["position"][idx], sc["velocity"][idx], idx, slab))
+sigs = {b.liquid_signature() for b in backs} - {0}
+compact = len(sigs) == 1 and 0xffffffff not in sigs and os.environ.get("SPHMI_SLAB_FULL_RECORDS", "0") == "0"
+if compact:  # what SlabDecomposition agrees on across ranks: 7-word records
+    for b in backs:
+        b.set_record_format(7, next(iter(sigs)))
+REC = backs[0].record_words
+framed = os.environ.get("SPHMI_SLAB_SYNC_EXCHANGE", "0") == "0"  # rebuild with device-side counts (no host round trip before the merge)
 mid = backs[1]
+print("record words", REC, "| rebuild:", "framed, counts on the device" if framed else "host counts")
 print("local particles per slab:", [b.count for b in backs], "owned ~", n_global // world, "overlap", overlap)
 
 
@@ -42,10 +50,11 @@ def produce(b, it):
     return b.pack_framed()
 
 
-def received(frames, r):
-    """(from lower, from upper) payload views for slab r out of everybody's frames."""
-    lo = None if r == 0 else frames[r - 1][3][1:1 + frames[r - 1][4]]      # lower neighbour's UP frame
-    up = None if r == world - 1 else frames[r + 1][1][1:1 + frames[r + 1][2]]  # upper neighbour's DOWN frame
+def received(frames, r, whole=False):
+    """(from lower, from upper) payload views for slab r out of everybody's frames (whole: the frames [count | payload])."""
+    a = 0 if whole else 1
+    lo = None if r == 0 else frames[r - 1][3][a:1 + frames[r - 1][4]]      # lower neighbour's UP frame
+    up = None if r == world - 1 else frames[r + 1][1][a:1 + frames[r + 1][2]]  # upper neighbour's DOWN frame
     return lo, up
 
 
@@ -61,11 +70,11 @@ for it in range(steps + 3):
     t0 = time.perf_counter()
     frames[1] = produce(mid, it)
     tp = time.perf_counter()
-    lo, up = received(frames, 1)
+    lo, up = received(frames, 1, whole=framed)
     lo, up = lo.clone(), up.clone()          # the transfer: two device copies of the size RCCL would move ...
     if os.environ.get("SPHMI_DEBUG_SORTED"):
         for nm, t in (("lo", lo), ("up", up)):
-            g = t.cpu().numpy().view(np.uint32).reshape(-1, REC)[:, 8].astype(np.int64)
+            g = t.cpu().numpy().view(np.uint32)[(1 if framed else 0):].reshape(-1, REC)[:, REC - 1].astype(np.int64)
             print(it, nm, g.size, bool(np.all(np.diff(g) > 0)), flush=True)
     torch.cuda.current_stream().synchronize()
     if delay:
@@ -73,7 +82,12 @@ for it in range(steps + 3):
         while time.perf_counter() - t1 < delay:  # ... plus the host-side latency of issuing and completing it
             pass
     tr = time.perf_counter()
-    mid.rebuild(lo, up)
+    if framed:   # enqueued behind the transfer without the host knowing any count; the count is collected once, at the end
+        mid.wait_for(torch.cuda.current_stream())
+        mid.rebuild_framed(lo, up)
+        assert not mid.rebuild_finish()[3]
+    else:
+        mid.rebuild(lo, up)
     mid.solver.synchronize()
     dt = time.perf_counter() - t0
     if it >= 3:
@@ -101,5 +115,6 @@ if os.environ.get("SPHMI_STAGES"):  # per-stage device times of the middle slab 
     print("  stages (ms/step):", {n: round(ms / k, 4) for n, (ms, c) in st.items() if c})
 times = np.array(times) * 1e3
 print("  until frames ready %.3f ms, transfer emulation %.3f ms, rebuild incl. wait for the step %.3f ms" % tuple(np.array(parts).mean(0) * 1e3))
+print("  bytes per message to the middle slab: %d + %d" % (4 * lo.numel(), 4 * up.numel()))
 print("interior rank: %.3f ms/step (p50 %.3f) for %d local / %d owned particles, emulated transfer delay %.0f us" % (
     times.mean(), np.median(times), mid.count, n_global // world, delay * 1e6))
