@@ -459,11 +459,21 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   // the few set bits are turned into list entries in traversal order.
   const float r2f = sh.binU[63];  // max(h, 31h/30)^2 * (1 + 2^-20), computed on the host
   const f32x2 nthr = {-r2f, -r2f};
+  // m - c as fma(c, -1, m): the same value, but v_pk_fma_f32 issues faster than v_pk_add_f32 (tools/micro/valu_rates.hip: 5.5 vs
+  // 6.7 cycles per wave instruction at two waves per SIMD). The -1 is opaque so that the compiler does not turn it back.
+  float neg1s = -1.f;
+  asm volatile("" : "+s"(neg1s));
+  const f32x2 neg1 = {neg1s, neg1s};
   uint16_t (*const myList)[64] = sh.list[wave];
+#ifdef FN_SUB_BY_ADD  // A/B: the differences as v_pk_add_f32 with negated operands (6.7 cycles each against 5.5 for v_pk_fma_f32)
+#define FN_DIFF(m, c) ((m) - (c))
+#else
+#define FN_DIFF(m, c) __builtin_elementwise_fma((c), neg1, (m))
+#endif
 #define FN_TEST(X, Y, Z)                                                                        \
   {                                                                                             \
-    const f32x2 ex0 = mx - X.xy, ex1 = mx - X.zw, ey0 = my - Y.xy, ey1 = my - Y.zw;             \
-    const f32x2 ez0 = mz - Z.xy, ez1 = mz - Z.zw;                                               \
+    const f32x2 ex0 = FN_DIFF(mx, X.xy), ex1 = FN_DIFF(mx, X.zw), ey0 = FN_DIFF(my, Y.xy), ey1 = FN_DIFF(my, Y.zw); \
+    const f32x2 ez0 = FN_DIFF(mz, Z.xy), ez1 = FN_DIFF(mz, Z.zw);                               \
     const f32x2 s0 = __builtin_elementwise_fma(ez0, ez0, __builtin_elementwise_fma(ey0, ey0, __builtin_elementwise_fma(ex0, ex0, nthr))); \
     const f32x2 s1 = __builtin_elementwise_fma(ez1, ez1, __builtin_elementwise_fma(ey1, ey1, __builtin_elementwise_fma(ex1, ex1, nthr))); \
     acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s0.x), 31);                            \
