@@ -432,7 +432,7 @@ def rank_main(args):
     # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step,
     # owPhysicsFluidSimulator.cpp:115) — waited for like the reference does, and started asynchronously so that the copy
     # runs under the next step (sph_read_position_async; the data is complete after the final wait).
-    p50_ms, readback_ms, readback_blocking_ms = None, None, None
+    p50_ms, readback_ms, readback_blocking_ms, readback_plain_ms = None, None, None, None
     if world == 1:
         k3 = max(5, min(args.steps, 50))
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(k3 + 1)]
@@ -445,18 +445,27 @@ def rank_main(args):
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
         p50_ms = per_step[len(per_step) // 2]
         host_pos = np.empty((N, 4), np.float32)
-        k3 = 50  # (the last copy's ~6 ms are not hidden by anything: amortised over 50 steps whatever --steps says)
-        solver.read_position_buffer_async(host_pos)  # (page-locks host_pos once, outside the timed loop)
+        solver.read_position_buffer_async(host_pos)  # (page-locks host_pos once, outside the timed loops)
         solver.wait_position_buffer()
-        solver.synchronize()
-        r0 = time.perf_counter()
-        for _ in range(k3):
-            stepper.step(it); it += 1
-            solver.read_position_buffer_async(host_pos)
-        solver.wait_position_buffer()
-        solver.synchronize()
-        readback_ms = (time.perf_counter() - r0) * 1e3 / k3
-        kb = max(3, k3 // 5)
+        # A box's clocks drift while it is loaded (the same loop is up to 8 % slower a few seconds into the run), so the step with
+        # the read-back is timed INTERLEAVED with the same loop without it: plain, async, plain, async, 50 steps each (the last
+        # copy's ~6 ms are not hidden by anything: amortised over 50 steps whatever --steps says).
+        seg = {"plain": [], "async": []}
+        for _ in range(2):
+            for kind in ("plain", "async"):
+                solver.synchronize()
+                r0 = time.perf_counter()
+                for _ in range(50):
+                    stepper.step(it); it += 1
+                    if kind == "async":
+                        solver.read_position_buffer_async(host_pos)
+                if kind == "async":
+                    solver.wait_position_buffer()
+                solver.synchronize()
+                seg[kind].append((time.perf_counter() - r0) * 1e3 / 50)
+        readback_ms = sum(seg["async"]) / 2
+        readback_plain_ms = sum(seg["plain"]) / 2
+        kb = 10
         r0 = time.perf_counter()
         for _ in range(kb):
             stepper.step(it); it += 1
@@ -522,6 +531,7 @@ def rank_main(args):
             "ms_per_step_p50": None if p50_ms is None else round(p50_ms, 4),
             "ms_per_step_with_position_readback": None if readback_ms is None else round(readback_ms, 4),
             "ms_per_step_with_blocking_position_readback": None if readback_blocking_ms is None else round(readback_blocking_ms, 4),
+            "ms_per_step_same_pass_without_readback": None if readback_plain_ms is None else round(readback_plain_ms, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms, "stages_frac": stages_frac,
             "radix_sort_passes": sort_passes, "lib": lib,
         }

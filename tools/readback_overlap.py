@@ -10,7 +10,13 @@ big = not (len(sys.argv) > 2 and sys.argv[2] == "1M")
 sc = scenes.liquid_box((78.0, 50.0, 470.0), (160, 100, 1000), mask=0xffffffff) if big else scenes.liquid_box((50.0, 50.0, 50.0), (100, 100, 100))
 N = sc["cfg"].particleCount
 h = scenes.hip_for(sc)
-host = np.empty((N, 4), np.float32)
+if len(sys.argv) > 3 and sys.argv[3] == "pinned":   # hipHostMalloc'ed by torch instead of page-locked in place by hipHostRegister
+    import torch
+    keep = torch.empty((N, 4), dtype=torch.float32, pin_memory=True)
+    host = keep.numpy()
+else:
+    host = np.empty((N, 4), np.float32)
+print("destination:", "torch pinned (hipHostMalloc)" if len(sys.argv) > 3 and sys.argv[3] == "pinned" else "numpy, page-locked in place (hipHostRegister)")
 it = 0
 for _ in range(5):
     h.step(it); it += 1
