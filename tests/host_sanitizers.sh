@@ -29,6 +29,10 @@ p, v, counts = sphmi.load_configuration(d + "/p.txt", d + "/v.txt")
 assert (p == b["position"]).all()
 sphmi.save_configuration(d, sc["position"], sc["numOfElasticP"], sc["numOfLiquidP"], sc["elastic"], sc["membranes"], True)
 sphmi.muscle_signal(5)
+cfgw = scenes.liquid_box_config((8.0, 8.0, 40.0), mask=0xffffffff)
+hist = sphmi.box_layer_histogram(cfgw, 12, 10, 60)
+ps, vs, gs = sphmi.generate_box_slice(cfgw, 12, 10, 60, 2, 7)
+assert gs.size == hist[2:7].sum() and sum(sphmi.box_counts(cfgw, 12, 10, 60)) == hist.sum()
 print("host library ok")
 for name in ("tiny_jitter", "tiny_elastic", "alias16"):
     o = scenes.oracle_for(scenes.SCENES[name](), threads=2)
