@@ -96,16 +96,20 @@ def host_cores():
 # non-zero status instead of hanging until somebody's outer limit: inside each rank a daemon thread checks the rank's own last
 # beat (covers ranks started by the driver's torch.distributed.run), and the self-launcher checks every rank's heartbeat file.
 WATCHDOG_S = float(os.environ.get("SPHMI_WATCHDOG_S", "120"))
-_last_beat = [time.monotonic(), "start"]
+# start-up phases (the first `import torch` on a fresh box takes 1-2 minutes, an 8-rank RCCL rendezvous tens of seconds) may be
+# silent for longer than a step may
+STARTUP_S = float(os.environ.get("SPHMI_WATCHDOG_STARTUP_S", str(max(600.0, WATCHDOG_S))))
+_last_beat = [time.monotonic(), "start", STARTUP_S]
 
 
-def beat(phase):
-    _last_beat[0], _last_beat[1] = time.monotonic(), phase
+def beat(phase, startup=False):
+    limit = STARTUP_S if startup else WATCHDOG_S
+    _last_beat[0], _last_beat[1], _last_beat[2] = time.monotonic(), phase, limit
     d = os.environ.get("SPHMI_HEARTBEAT_DIR")
     if d:
         try:
             with open(os.path.join(d, "rank%s" % os.environ.get("RANK", "0")), "w") as f:
-                f.write(phase)
+                f.write("%g|%s" % (limit, phase))
         except OSError:
             pass
 
@@ -115,7 +119,7 @@ def start_rank_watchdog(rank):
         while True:
             time.sleep(min(5.0, max(0.2, WATCHDOG_S / 4)))
             idle = time.monotonic() - _last_beat[0]
-            if idle > WATCHDOG_S:
+            if idle > _last_beat[2]:
                 sys.stderr.write("bench.py watchdog: rank %d silent for %.0f s in phase '%s' — giving up\n" % (rank, idle, _last_beat[1]))
                 sys.stderr.flush()
                 os._exit(3)
@@ -156,11 +160,13 @@ def self_launch(args, argv):
         now = time.time()
         for r in range(args.gpus):
             f = os.path.join(hb, "rank%d" % r)
+            limit = STARTUP_S
             try:
-                idle, phase = now - os.path.getmtime(f), open(f).read()
-            except OSError:
+                idle, text = now - os.path.getmtime(f), open(f).read()
+                limit, phase = float(text.split("|", 1)[0]), text.split("|", 1)[1]
+            except (OSError, ValueError, IndexError):
                 idle, phase = time.monotonic() - started, "not started"
-            if idle > WATCHDOG_S + 10.0:  # (the rank's own watchdog fires first; this one covers a rank that cannot even do that)
+            if idle > limit + 10.0:  # (the rank's own watchdog fires first; this one covers a rank that cannot even do that)
                 hung = (r, idle, phase)
         if hung:
             sys.stderr.write("bench.py: rank %d silent for %.0f s in phase '%s': ending the run\n" % hung)
@@ -231,7 +237,7 @@ def rank_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py --gpus %d but WORLD_SIZE=%d: start it with --nproc-per-node %d (or without a launcher)" % (args.gpus, world, args.gpus))
-    beat("imports")
+    beat("imports", startup=True)
     if world > 1:
         start_rank_watchdog(rank)
 
@@ -250,7 +256,7 @@ def rank_main(args):
         # it is also what a run with fewer cards than ranks falls back to (RCCL refuses two ranks on one device)
         ndev = torch.cuda.device_count()
         backend_name = os.environ.get("SPHMI_DIST_BACKEND") or ("nccl" if ndev >= world else "gloo")
-        beat("rendezvous (%s)" % backend_name)
+        beat("rendezvous (%s)" % backend_name, startup=True)
         if not args.dry_run:
             local_rank = local_rank % max(1, ndev)
             torch.cuda.set_device(local_rank)
@@ -259,7 +265,7 @@ def rank_main(args):
         else:
             dist.init_process_group(backend_name, rank=rank, world_size=world)
         dist.barrier()  # creates the communicator with every rank present before the first point-to-point exchange
-        beat("rendezvous done")
+        beat("rendezvous done", startup=True)
     comm_dev = "cuda" if backend_name == "nccl" else "cpu"
     if args.dry_run:
         if world == 1:
@@ -285,7 +291,7 @@ def rank_main(args):
 
     decomposition = None
     stream = None
-    beat("scene")
+    beat("scene", startup=True)
     if world > 1:
         # Every rank builds only ITS slice of the scene (own layers + ghost layers) from the generator, after cutting the box with
         # the per-layer histogram — no rank ever holds the 16.5 M-particle arrays (N x 528 MB of host copies otherwise).
@@ -301,7 +307,7 @@ def rank_main(args):
         own_lo = slab.layerLo - slab.ghostLayers if slab.hasLower else S.OPEN_LO
         own_hi = slab.layerHi + slab.ghostLayers if slab.hasUpper else S.OPEN_HI
         pos_l, vel_l, gid_l = sphmi.generate_box_slice(cfg, *lattice, own_lo, own_hi)
-        beat("scene slice: %d particles" % gid_l.size)
+        beat("scene slice: %d particles" % gid_l.size, startup=True)
         if args.dry_run:
             return dry_run_report(args, np, torch, dist, S, cfg, slab, pos_l, gid_l, N, rank, world, workload_name, backend_name)
         cfg.device = local_rank
@@ -327,7 +333,7 @@ def rank_main(args):
         N = cfg.particleCount  # global particle count
         solver = sphmi.owHIPSolver(cfg, sc["position"], sc["velocity"])
         stepper = solver
-    beat("solver ready")
+    beat("solver ready", startup=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -567,6 +573,7 @@ def density_sources_sha():
 def dry_run_report(args, np, torch, dist, S, cfg, slab, pos_l, gid_l, N, rank, world, workload_name, backend_name):
     """--dry-run: what every rank would hand its solver, checked across ranks — the owned sets of the slices partition the
     particles — and reported as a line without a value. Exercises launcher, rendezvous, cuts, slices, heartbeats."""
+    beat("dry run")
     if os.environ.get("SPHMI_BENCH_TEST_HANG_RANK") == str(rank):  # test hook: this rank goes silent (watchdog test)
         time.sleep(3600)
     lay = S.particle_layers(pos_l, cfg)
