@@ -394,9 +394,11 @@ class SlabDecomposition:
     # waits for the receive through an event; the rebuild reads the received counts on the device; the new local count (and
     # whether a message outgrew its agreed frame) is collected by finish() at the start of the next step.
     def _can_run_async(self):
-        return (self.overlap and self.world > 1 and self.comm_device.type == "cuda" and hasattr(self.backend, "rebuild_framed")
-                and hasattr(self.backend, "step_and_pack_framed") and getattr(self.backend, "frame_device", None) == self.comm_device
-                and not os_environ_flag("SPHMI_SLAB_SYNC_EXCHANGE"))
+        # (HipSlabBackend under RCCL; the protocol itself does not care where the frames live, and the CPU tests run it over gloo
+        # with a backend that offers the same four calls)
+        return (self.overlap and self.world > 1 and all(hasattr(self.backend, m) for m in ("rebuild_framed", "rebuild_finish",
+                                                                                           "step_and_pack_framed", "wait_for"))
+                and getattr(self.backend, "frame_device", None) == self.comm_device and not os_environ_flag("SPHMI_SLAB_SYNC_EXCHANGE"))
 
     def _exchange_async(self, prepacked):
         torch, dist = self.torch, self.dist
@@ -416,7 +418,8 @@ class SlabDecomposition:
         ops = [dist.P2POp(dist.isend, out[p], p) for p in peers] + [dist.P2POp(dist.irecv, inn[p], p) for p in peers]
         for w in dist.batch_isend_irecv(ops):
             w.wait()  # torch's current stream waits for RCCL — the host does not
-        self.backend.wait_for(torch.cuda.current_stream(self.comm_device))  # ... and the solver's stream waits for that
+        # ... and the solver's stream waits for that
+        self.backend.wait_for(torch.cuda.current_stream(self.comm_device) if self.comm_device.type == "cuda" else None)
         self.backend.rebuild_framed(inn.get(self.lower), inn.get(self.upper))
         self.bytes_sent += sum(4 * out[p].numel() for p in peers)
         self.transfers += 1

@@ -61,8 +61,13 @@ class OracleSlabBackend:
         self.cfg, self.slab = cfg, slab
         self.pos, self.vel, self.gid = position.copy(), velocity.copy(), global_ids.copy()
         self.owned = self._owned(self.pos)
-        if os.environ.get("SPHMI_TEST_FRAMED"):
+        if os.environ.get("SPHMI_TEST_FRAMED") or os.environ.get("SPHMI_TEST_ASYNC"):
             self.frame_device = torch.device("cpu")
+        if os.environ.get("SPHMI_TEST_ASYNC"):  # the four calls of the asynchronous exchange (sphmi/slab.py), in numpy
+            self.step_and_pack_framed = self._step_and_pack_framed
+            self.rebuild_framed = self._rebuild_framed
+            self.rebuild_finish = self._rebuild_finish
+            self.wait_for = lambda stream: None
 
     def _owned(self, pos):
         lay = S.particle_layers(pos, self.cfg)
@@ -123,6 +128,28 @@ class OracleSlabBackend:
             frames.append(f)
         return kept, frames[0], int(down.numel()), frames[1], int(up.numel())
 
+    def _step_and_pack_framed(self, iteration):
+        self.step(iteration)
+        kept, fd, nd, fu, nu = self.pack_framed()
+        return None, fd, nd, fu, nu
+
+    def _rebuild_framed(self, frame_down, frame_up):
+        """What sph_slab_rebuild_framed does: lengths from word 0 of the frames; nothing is merged if a frame is too short."""
+        W = self.record_words
+        counts, payloads, ok = [], [], True
+        for f in (frame_down, frame_up):
+            n = 0 if f is None else int(f[0]) // W
+            cap = 0 if f is None else (f.numel() - 1) // W
+            ok = ok and n <= cap
+            counts.append(n)
+            payloads.append(None if f is None else f[1:1 + min(n, cap) * W])
+        self._framed = (int(self._kept[0].shape[0]), counts[0], counts[1], not ok)
+        if ok:
+            self.rebuild(payloads[0], payloads[1])
+
+    def _rebuild_finish(self):
+        return self._framed
+
     def rebuild(self, recv_down, recv_up):
         parts = [self._kept]
         W = self.record_words
@@ -178,12 +205,13 @@ def main():
     dd = S.SlabDecomposition(backend, a.rank, a.world, dist, comm_device="cpu")  # gloo: messages staged through host
     counts = []
     for it in range(a.steps):
-        counts.append(dd.step(it))
-    dd.finish()
+        n = dd.step(it)
+        counts.append(-1 if n is None else n)  # (asynchronous exchange: the count arrives with finish())
+    counts[-1] = dd.finish()
     gid, p, v = backend.owned_state()
     first_owner = np.searchsorted(np.array(cuts[1:-1]), layers, side="right")  # rank that owned each particle at the start
     np.savez(os.path.join(a.out, "rank%d.npz" % a.rank), gid=gid, pos=p, vel=v, counts=np.array(counts),
-             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers, record_words=dd.rec,
+             cuts=np.array(cuts), sent=dd.bytes_sent, transfers=dd.transfers, record_words=dd.rec, asynchronous=dd._can_run_async(),
              adopted=int((first_owner[gid.astype(np.int64)] != a.rank).sum()))  # owned now, owned by another rank at the start
     dist.barrier()
     dist.destroy_process_group()

@@ -147,6 +147,20 @@ def test_halo_payload_larger_than_the_agreed_bound_cpu(tmp_path):
     assert all(int(r["transfers"]) == 2 * 3 for r in results)
 
 
+@pytest.mark.parametrize("env", [{}, {"SPHMI_TEST_BOUND_WORDS": "36"}, {"SPHMI_TEST_VZ": "0.6"}])
+def test_asynchronous_exchange_protocol_cpu(tmp_path, env):
+    """The protocol of the RCCL path — frames sent at their agreed length without the host knowing a count, rebuild from the frames,
+    counts collected at the start of the next step, a frame that was too short completed by a second transfer there — run over
+    gloo with the oracle backend offering the same four calls as HipSlabBackend (the GPU suite runs it on real RCCL)."""
+    steps = 5
+    results = run_ranks("oracle", 3, tmp_path, steps=steps, env=dict(env, SPHMI_TEST_ASYNC="1"))
+    sc, pos_ref, vel_ref = single_domain_reference(steps=steps, env=env)
+    check_union(results, sc, pos_ref, vel_ref)
+    assert all(bool(r["asynchronous"]) for r in results)
+    expect = 2 * steps if "SPHMI_TEST_BOUND_WORDS" in env else steps + 1
+    assert all(int(r["transfers"]) == expect for r in results)
+
+
 def test_three_rank_halo_exchange_matches_single_domain_cpu(tmp_path):
     results = run_ranks("oracle", 3, tmp_path, steps=3)
     sc, pos_ref, vel_ref = single_domain_reference(steps=3)
