@@ -68,7 +68,9 @@ __device__ __forceinline__ int wrap_cell(int c, int G) {  // searchCell, sphFlui
   return c;
 }
 
-#define FN_PART 128               // particles per workgroup
+#ifndef FN_PART
+#define FN_PART 128               // particles per workgroup (A/B: 256 particles / 512 threads / one workgroup per CU)
+#endif
 #ifndef FN_LANES
 #define FN_LANES 2                // lanes per particle: 2 (a pair; whole cells) or 4 (a DPP quad: pairs x cell halves). A/B on MI355X,
 #endif                            // config #2: 2 lanes 0.44 ms, 4 lanes 0.58 ms (more waves per SIMD, but 30 % more instructions)
@@ -249,7 +251,7 @@ __device__ __forceinline__ void fn_exact_walk(const FnParams& d, const FnArrays&
 // Synchronisation: ONE workgroup barrier per batch, between the staging of the candidates and their use. Everything before it
 // (batch bounds, the 9 candidate runs, their LDS layout) is computed redundantly by every wave from loads with workgroup-uniform
 // addresses, everything after it is private to a wave (its lists, its d^2 staging area, the exact walks of its own particles).
-__global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_neighbors(FnParams d, const float4* __restrict__ sortedPos,
+__global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : (FN_PART > 128 ? 1 : 2))) void k_find_neighbors(FnParams d, const float4* __restrict__ sortedPos,
                                                                    const uint32_t* __restrict__ keys,
                                                                    const uint32_t* __restrict__ cellStart,
                                                                    const float* __restrict__ binU, int32_t* __restrict__ nbrId,
@@ -290,12 +292,16 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : 2)) void k_find_ne
   int batchHi = blockHi;
   if (retry) {  // every wave finds the end of the batch itself (same data, same answer)
     const unsigned row0 = keys[batchLo] / (unsigned)d.gx;
-    const int i0 = batchLo + lane, i1 = batchLo + 64 + lane;  // the workgroup's <= 128 particles, two per lane
-    const bool stop0 = (i0 >= blockHi) || (keys[min(i0, blockHi - 1)] / (unsigned)d.gx != row0) || (retry == 2 && lane >= 32);
-    const bool stop1 = (i1 >= blockHi) || (keys[min(i1, blockHi - 1)] / (unsigned)d.gx != row0) || (retry == 2);
-    const unsigned long long m0 = __ballot(stop0), m1 = __ballot(stop1);
-    batchHi = batchLo + (m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128));  // first particle that must not join
-    batchHi = min(batchHi, blockHi);
+    // the workgroup's <= FN_PART particles, 64 per round: the first one that must not join ends the batch
+    int firstStop = FN_PART;
+#pragma unroll
+    for (int q = FN_PART / 64 - 1; q >= 0; q--) {
+      const int iq = batchLo + 64 * q + lane;
+      const bool stopq = (iq >= blockHi) || (keys[min(iq, blockHi - 1)] / (unsigned)d.gx != row0) || (retry == 2 && (q > 0 || lane >= 32));
+      const unsigned long long mq = __ballot(stopq);
+      if (mq) firstStop = 64 * q + __ffsll((long long)mq) - 1;
+    }
+    batchHi = min(batchLo + firstStop, blockHi);
   }
   // The dependent global round trips below are on the workgroup's critical path: (1) the batch's first / last cell, (2) the
   // two ends of the 9 runs, (3) all candidate records at once, flat over the concatenated runs, together with the cell-table
