@@ -465,10 +465,12 @@ __global__ __launch_bounds__(FN_THREADS, (FN_LANES == 4 ? 4 : (FN_PART > 128 ? 1
   // the few set bits are turned into list entries in traversal order.
   const float r2f = sh.binU[63];  // max(h, 31h/30)^2 * (1 + 2^-20), computed on the host
   const f32x2 nthr = {-r2f, -r2f};
-  // m - c as fma(c, -1, m): the same value, but v_pk_fma_f32 issues faster than v_pk_add_f32 (tools/micro/valu_rates.hip: 5.5 vs
-  // 6.7 cycles per wave instruction at two waves per SIMD). The -1 is opaque so that the compiler does not turn it back.
+  // m - c as fma(c, -1, m): the same value; v_pk_fma_f32 measures faster than v_pk_add_f32 in isolation (tools/micro/valu_rates.hip:
+  // 5.5 vs 6.7 cycles per wave instruction at two waves per SIMD), in this kernel it is worth 0.6 % — what counts here is the
+  // NUMBER of vector instructions (SQ_ACTIVE_INST_VALU = one slot each, 72 % of the SIMD's time), not their kind. The -1 is opaque
+  // so that the compiler does not turn the fma back into a subtraction.
   float neg1s = -1.f;
-  asm volatile("" : "+s"(neg1s));
+  asm volatile("" : "+s"(neg1s));  // (a scalar pair; held in a vector pair instead: the same time)
   const f32x2 neg1 = {neg1s, neg1s};
   uint16_t (*const myList)[64] = sh.list[wave];
 #ifdef FN_SUB_BY_ADD  // A/B: the differences as v_pk_add_f32 with negated operands (6.7 cycles each against 5.5 for v_pk_fma_f32)
