@@ -280,8 +280,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_sort_post(SphDev d) {
 // cellStart[c] = number of particles whose cell id is < c (lower bound in the sorted keys). For a non-empty cell that
 // is its first sorted index (what the reference's binary search finds); for an empty one it is the start of the next
 // non-empty cell (what the backward fill writes); [0] = 0 and [G] = N. The key array is L2-resident (4 B/particle).
-__global__ __launch_bounds__(SPH_BLOCK) void k_cell_start(SphDev d) {
-  const int c = blockIdx.x * SPH_BLOCK + threadIdx.x;
+// Slab mode: only cells [first, last) are computed — the layers the slab's particles and their neighbour cells can lie in — plus
+// the two ends of the table, which ranged launches read (sph_ranged: cellStart[0], cellStart[G]).
+__global__ __launch_bounds__(SPH_BLOCK) void k_cell_start(SphDev d, int first, int last) {
+  int c = first + blockIdx.x * SPH_BLOCK + threadIdx.x;
+  if (c >= last) {
+    if (c == last) c = 0; else if (c == last + 1) c = d.G; else return;  // two spare lanes take the table's ends
+  }
   if (c > d.G) return;
   int lo = 0, hi = d.N;  // first index in [0, N] whose key is >= c
   while (lo < hi) {
@@ -297,7 +302,17 @@ int sphk_sort_post(sph_solver* s) {
   return SPH_OK;
 }
 int sphk_index_fixed(sph_solver* s) {
-  hipLaunchKernelGGL(k_cell_start, dim3(sph_blocks(s->d.G + 1)), dim3(SPH_BLOCK), 0, s->stream, s->d);
+  int first = 0, last = s->d.G + 1;
+  if (s->hasSlab) {
+    // A slab's particles lie in its own layers +- ghostLayers; the search reads the table for their cells, the cells one layer
+    // up and down and two cells beyond a run's end: layers [layerLo - W - 2, layerHi + W + 3) cover that. The declared grid is the
+    // global one (39 us of binary searches per step at 16.5 M cells, whatever the rank's share of the particles).
+    const long long layerCells = (long long)s->d.gx * s->d.gy, W = s->slab.ghostLayers;
+    const long long lo = max((long long)s->slab.layerLo - W - 2, 0LL) * layerCells;
+    const long long hi = min(((long long)s->slab.layerHi + W + 3) * layerCells, (long long)s->d.G + 1);
+    first = (int)min(lo, (long long)s->d.G + 1); last = (int)max(hi, (long long)first);
+  }
+  hipLaunchKernelGGL(k_cell_start, dim3(sph_blocks(last - first + 2)), dim3(SPH_BLOCK), 0, s->stream, s->d, first, last);
   SPH_HIP(hipGetLastError());
   return SPH_OK;
 }
