@@ -33,6 +33,9 @@ extern "C" const char* sph_build_info(void) {
 #ifdef DIAG_NO_WALK
          " DIAG_NO_WALK(invalid results)"
 #endif
+#ifdef DIAG_DENSITY_INTO_REC
+         " DIAG_DENSITY_INTO_REC(invalid results)"
+#endif
 #ifdef DIAG_NO_REPLAY
          " DIAG_NO_REPLAY(invalid results)"
 #endif

@@ -158,7 +158,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_density(SphDev d, int nblocks) {
     }
     if (density < (double)d.hs6) density = (double)d.hs6;
     density *= d.massWpoly6;
+#ifdef DIAG_DENSITY_INTO_REC  // timing experiment (results invalid): the density as a 4-byte store into the gather record's half-line
+    reinterpret_cast<float*>(&d.gatherRec[rec_index(id, 1)])[3] = (float)density;
+#else
     d.rho[id] = (float)density;
+#endif
   }
 }
 

@@ -8,7 +8,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 box, lat, mask = WORK[name]
 sc = scenes.liquid_box(box, lat, mask=mask)
 h = scenes.hip_for(sc)
-for it in range(3): h.step(it)
+if not os.environ.get("SPHMI_NO_STEPS"):  # (diagnostic builds with invalid results must not integrate)
+    for it in range(3): h.step(it)
 h._runClearBuffers(); h._runHashParticles(); h._runSort(); h._runSortPostPass(); h._runIndexx(); h._runIndexPostPass(); h._runFindNeighbors()
 for _ in range(3): h._run_pcisph_computeDensity()
 h.synchronize(); h.set_stage_timing(True); h.reset_stage_times()
