@@ -563,11 +563,15 @@ def rank_main(args):
 
 
 def density_sources_sha():
-    """Hash of the sources k_density is compiled from: profiles/density_traffic.json is only quoted for these."""
-    h = hashlib.sha256()
-    for f in ("sph_pcisph.hip", "sph_common.h"):
-        h.update(open(os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd", "csrc", f), "rb").read())
-    return h.hexdigest()
+    """Hash of the source text k_density is compiled from — its section of sph_pcisph.hip (K6 header comment up to the K9 header),
+    the NbrTile accessor it reads the map through and nbr_index(): profiles/density_traffic.json is only quoted for these."""
+    src = open(os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd", "csrc", "sph_pcisph.hip")).read()
+    common = open(os.path.join(ROOT, "smoothed-particle-hydrodynamics_amd", "csrc", "sph_common.h")).read()
+    parts = [src[src.index("// ------------------------------------------------------------------ K6 pcisph_computeDensity"):
+                 src.index("// ------------------------------------------------------------------ K9 pcisph_predictPositions")],
+             src[src.index("struct NbrTile {"):src.index("// XCD-aware block order")],
+             common[common.index("// index of (sorted particle id, slot) in the tiled neighbour map"):common.index("// The neighbour ids a second time")]]
+    return hashlib.sha256("\n".join(parts).encode()).hexdigest()
 
 
 def dry_run_report(args, np, torch, dist, S, cfg, slab, pos_l, gid_l, N, rank, world, workload_name, backend_name):
