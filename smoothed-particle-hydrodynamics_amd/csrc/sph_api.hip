@@ -1093,7 +1093,10 @@ extern "C" int sph_slab_rebuild(sph_solver* s, const void* recvDown, int32_t nDo
 extern "C" int sph_slab_rebuild_framed(sph_solver* s, const void* frameDown, int32_t capDownRecords, const void* frameUp,
                                        int32_t capUpRecords) {
   ENTER(s);
-  if (!s->hasSlab || capDownRecords < 0 || capUpRecords < 0) { sph_set_error("sph_slab_rebuild_framed: bad arguments"); return SPH_ERR_INVALID; }
+  if (!s->hasSlab || capDownRecords < 0 || capUpRecords < 0 || (s->slab.hasLower && !frameDown) || (s->slab.hasUpper && !frameUp)) {
+    sph_set_error("sph_slab_rebuild_framed: slab not initialised, negative capacity, or no frame from a neighbour that exists");
+    return SPH_ERR_INVALID;
+  }
   const uint32_t* keptPtr;
   if (s->slabStepPending) keptPtr = s->slabCounts + 8;       // overlapped step: the kept pass of sph_slab_step_begin
   else if (s->slabKept >= 0) keptPtr = s->slabCounts + 0;    // sph_slab_pack / sph_slab_pack_framed
