@@ -62,8 +62,18 @@ struct NbrTile {
     zOff = d.nbrBase[id] - id;
   }
   __device__ __forceinline__ int4 id4(int g) const { return ids[(size_t)g * 64]; }
-  __device__ __forceinline__ float4 dist4(int g) const { return dist[(size_t)g * 64]; }
-  __device__ __forceinline__ uint2 vec16(int g) const { return v16[(size_t)g * 64]; }  // slots 4g .. 4g+3
+  // The rows are streamed once per kernel: non-temporal loads keep them from displacing the records the gathers live on
+  // (A/B at 16.5 M, profiles/r03/gather_rows_nontemporal_ab.txt: predictDensity 0.498 -> 0.490 ms, forces 1.549 -> 1.529, pressure force unchanged)
+  __device__ __forceinline__ float4 dist4(int g) const {
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    const nt4 q = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(&dist[(size_t)g * 64]));
+    return make_float4(q.x, q.y, q.z, q.w);
+  }
+  __device__ __forceinline__ uint2 vec16(int g) const {  // slots 4g .. 4g+3
+    typedef unsigned int nt2 __attribute__((ext_vector_type(2)));
+    const nt2 q = __builtin_nontemporal_load(reinterpret_cast<const nt2*>(&v16[(size_t)g * 64]));
+    return make_uint2(q.x, q.y);
+  }
   // the row has no 16-bit copy (an offset did not fit, or findNeighbors served the particle by its exact walk): use id_wide()
   __device__ __forceinline__ static bool wide(const uint2& group0) { return (group0.x & 0xffffu) == SPH_N16_WIDE; }
   __device__ __forceinline__ int id_wide(int slot) const {
