@@ -403,10 +403,11 @@ def rank_main(args):
         # per stage: algorithmic bytes of all its launches in one step / its time / 8 TB/s (pure-liquid scenes)
         sort_passes = solver.step_sort_passes()
         algo = dict(STAGE_ALGO_BYTES, sort=24 * sort_passes)  # 24 B per particle and radix pass (2 or 3 passes)
-        stages_frac = {k: round(n_local * algo[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                       for k, v in stages_ms.items() if k in algo and v > 0}
+        # (single domain only: in slab mode the stages are launched on different layer ranges and grouped differently)
+        stages_frac = {} if world > 1 else {k: round(n_local * algo[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                            for k, v in stages_ms.items() if k in algo and v > 0}
         step_ms = sum(stages_ms.values())
-        if step_ms > 0:
+        if step_ms > 0 and world == 1:
             stages_frac["whole_step_2600B"] = round(n_local * 2600.0 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             moved = sum(algo[k] for k in stages_ms if k in algo)
             stages_frac["whole_step_bytes_moved"] = moved
