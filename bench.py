@@ -364,6 +364,65 @@ def rank_main(args):
     ms_per_step = wall * 1e3 / args.steps
     value = N * args.steps / wall  # N = particles of the whole job (all ranks)
 
+    # SURVEY 8(d) extras, single GPU only and outside `value`, taken right after the timed region (a box's clocks drift while it
+    # is loaded: the same plain loop is up to 8 % slower a few seconds into the run): per-step p50 from one event pair per step, and
+    # the step with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step,
+    # owPhysicsFluidSimulator.cpp:115) — started asynchronously so that the copy runs under the next step
+    # (sph_read_position_async), timed INTERLEAVED with the same loop without it (plain, async, plain, async; 50 steps each), and
+    # waited for like the reference does.
+    #   ms_per_step_with_position_readback        steady state: device time per step of the async loop (events on the solver's stream,
+    #                                             from before the first step to after the last step's kernels — what a caller that
+    #                                             keeps stepping pays per step; the next integrate waits for the copy inside it)
+    #   ..._incl_final_copy                       wall time of the same loop / 50 including the wait for the LAST copy (~6 ms at
+    #                                             16.5 M that nothing can hide, i.e. +0.13 ms per step over 50 steps)
+    #   ms_per_step_same_pass_without_readback    the interleaved plain loop, same method as the steady-state figure
+    p50_ms, readback_ms, readback_blocking_ms, readback_plain_ms, readback_wall_ms = None, None, None, None, None
+    if world == 1:
+        host_pos = np.empty((N, 4), np.float32)
+        solver.read_position_buffer_async(host_pos)  # (page-locks host_pos once, outside the timed loops)
+        solver.wait_position_buffer()
+        seg = {"plain": [], "async": []}
+        wall_async = []
+        for _ in range(2):
+            for kind in ("plain", "async"):
+                solver.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                r0 = time.perf_counter()
+                with torch.cuda.stream(stream):
+                    e0.record(stream)
+                    for _ in range(50):
+                        stepper.step(it); it += 1
+                        if kind == "async":
+                            solver.read_position_buffer_async(host_pos)
+                    e1.record(stream)
+                if kind == "async":
+                    solver.wait_position_buffer()
+                solver.synchronize()
+                if kind == "async":
+                    wall_async.append((time.perf_counter() - r0) * 1e3 / 50)
+                seg[kind].append(e0.elapsed_time(e1) / 50)
+        readback_ms = sum(seg["async"]) / 2
+        readback_plain_ms = sum(seg["plain"]) / 2
+        readback_wall_ms = sum(wall_async) / 2
+        kb = 10
+        r0 = time.perf_counter()
+        for _ in range(kb):
+            stepper.step(it); it += 1
+            solver.read_position_buffer(host_pos)
+        readback_blocking_ms = (time.perf_counter() - r0) * 1e3 / kb
+        del host_pos
+        k3 = max(5, min(args.steps, 50))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k3 + 1)]
+        with torch.cuda.stream(stream):
+            evs[0].record(stream)
+            for i in range(k3):
+                stepper.step(it); it += 1
+                evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
+        p50_ms = per_step[len(per_step) // 2]
+    beat("read-back pass done")
+
     # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
     stages_ms, stages_frac, roofline, sort_passes = {}, {}, None, None
     if not args.no_stage_pass:
@@ -435,51 +494,6 @@ def rank_main(args):
         dist.all_gather(gathered, mine)
         per_rank = np.stack([g.cpu().numpy() for g in gathered])
 
-    # SURVEY 8(d) extras, single GPU only and outside `value`: per-step p50 from one event pair per step, and the step
-    # with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step,
-    # owPhysicsFluidSimulator.cpp:115) — waited for like the reference does, and started asynchronously so that the copy
-    # runs under the next step (sph_read_position_async; the data is complete after the final wait).
-    p50_ms, readback_ms, readback_blocking_ms, readback_plain_ms = None, None, None, None
-    if world == 1:
-        k3 = max(5, min(args.steps, 50))
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k3 + 1)]
-        with torch.cuda.stream(stream):
-            evs[0].record(stream)
-            for i in range(k3):
-                stepper.step(it); it += 1
-                evs[i + 1].record(stream)
-        torch.cuda.synchronize()
-        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
-        p50_ms = per_step[len(per_step) // 2]
-        host_pos = np.empty((N, 4), np.float32)
-        solver.read_position_buffer_async(host_pos)  # (page-locks host_pos once, outside the timed loops)
-        solver.wait_position_buffer()
-        # A box's clocks drift while it is loaded (the same loop is up to 8 % slower a few seconds into the run), so the step with
-        # the read-back is timed INTERLEAVED with the same loop without it: plain, async, plain, async, 50 steps each (the last
-        # copy's ~6 ms are not hidden by anything: amortised over 50 steps whatever --steps says).
-        seg = {"plain": [], "async": []}
-        for _ in range(2):
-            for kind in ("plain", "async"):
-                solver.synchronize()
-                r0 = time.perf_counter()
-                for _ in range(50):
-                    stepper.step(it); it += 1
-                    if kind == "async":
-                        solver.read_position_buffer_async(host_pos)
-                if kind == "async":
-                    solver.wait_position_buffer()
-                solver.synchronize()
-                seg[kind].append((time.perf_counter() - r0) * 1e3 / 50)
-        readback_ms = sum(seg["async"]) / 2
-        readback_plain_ms = sum(seg["plain"]) / 2
-        kb = 10
-        r0 = time.perf_counter()
-        for _ in range(kb):
-            stepper.step(it); it += 1
-            solver.read_position_buffer(host_pos)
-        readback_blocking_ms = (time.perf_counter() - r0) * 1e3 / kb
-        del host_pos
-    beat("read-back pass done")
 
     # CPU baseline: the oracle (bit-identical CPU restatement) on the same scene, all host cores, rank 0 only
     cpu = None
@@ -538,6 +552,7 @@ def rank_main(args):
             "ms_per_step_p50": None if p50_ms is None else round(p50_ms, 4),
             "ms_per_step_with_position_readback": None if readback_ms is None else round(readback_ms, 4),
             "ms_per_step_with_blocking_position_readback": None if readback_blocking_ms is None else round(readback_blocking_ms, 4),
+            "ms_per_step_with_position_readback_incl_final_copy": None if readback_wall_ms is None else round(readback_wall_ms, 4),
             "ms_per_step_same_pass_without_readback": None if readback_plain_ms is None else round(readback_plain_ms, 4),
             "roofline": roofline, "cpu_baseline": cpu, "stages_ms": stages_ms, "stages_frac": stages_frac,
             "radix_sort_passes": sort_passes, "lib": lib,
