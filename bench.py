@@ -364,8 +364,59 @@ def rank_main(args):
     ms_per_step = wall * 1e3 / args.steps
     value = N * args.steps / wall  # N = particles of the whole job (all ranks)
 
-    # SURVEY 8(d) extras, single GPU only and outside `value`, taken right after the timed region (a box's clocks drift while it
-    # is loaded: the same plain loop is up to 8 % slower a few seconds into the run): per-step p50 from one event pair per step, and
+    # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
+    stages_ms, stages_frac, roofline, sort_passes = {}, {}, None, None
+    if not args.no_stage_pass:
+        solver.set_stage_timing(True)
+        solver.reset_stage_times()
+        k2 = max(5, min(args.steps, 20))
+        for _ in range(k2):
+            stepper.step(it); it += 1
+        if decomposition is not None:
+            decomposition.finish()  # (collects the last asynchronous exchange: the local particle count)
+        st = solver.stage_times()
+        solver.set_stage_timing(False)
+        stages_ms = {k: round(ms / k2, 5) for k, (ms, cnt) in st.items() if cnt}
+        d_ms, d_cnt = st["density"]
+        n_local = solver.N  # particles this rank's density kernel processes per launch (incl. ghost layers when N > 1)
+        if d_cnt:
+            achieved = n_local * DENSITY_BYTES_PER_PARTICLE / (d_ms / d_cnt * 1e-3) / 1e9
+            roofline = {"kernel": "k_density (pcisph_computeDensity)", "bound": "hbm", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "avg_launch_us": round(d_ms / d_cnt * 1e3, 2),
+                        "bytes_per_launch": n_local * DENSITY_BYTES_PER_PARTICLE}
+            # HBM bytes from the committed rocprofv3 PMC passes of this workload (profiles/README.md) — NOT measured in this
+            # run (counters cannot be read from inside the process), and only quoted while the kernel sources are the ones the
+            # passes were taken on
+            traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
+            if os.path.exists(traffic_file) and world == 1:
+                tr = json.load(open(traffic_file))
+                entry = tr if tr.get("workload") == workload_name else tr.get("other_workloads", {}).get(workload_name)
+                if entry is not None:
+                    current = density_sources_sha()
+                    if tr.get("kernel_sources_sha256") in (None, current):
+                        roofline["traffic"] = entry.get("hbm_bytes_per_launch")
+                        roofline["traffic_source"] = "profiles/density_traffic.json (committed rocprofv3 PMC passes; not this run)"
+                    else:
+                        roofline["traffic_source"] = ("profiles/density_traffic.json is stale: measured on other kernel sources (%s..., now %s...)"
+                                                      % (tr["kernel_sources_sha256"][:12], current[:12]))
+        # per stage: algorithmic bytes of all its launches in one step / its time / 8 TB/s (pure-liquid scenes)
+        sort_passes = solver.step_sort_passes()
+        algo = dict(STAGE_ALGO_BYTES, sort=24 * sort_passes)  # 24 B per particle and radix pass (2 or 3 passes)
+        # (single domain only: in slab mode the stages are launched on different layer ranges and grouped differently)
+        stages_frac = {} if world > 1 else {k: round(n_local * algo[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                            for k, v in stages_ms.items() if k in algo and v > 0}
+        step_ms = sum(stages_ms.values())
+        if step_ms > 0 and world == 1:
+            stages_frac["whole_step_2600B"] = round(n_local * 2600.0 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            moved = sum(algo[k] for k in stages_ms if k in algo)
+            stages_frac["whole_step_bytes_moved"] = moved
+            stages_frac["whole_step_moved"] = round(n_local * moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    beat("stage pass done")
+
+    # SURVEY 8(d) extras, single GPU only and outside `value` (a box's clocks drift while it is loaded — the same plain loop is up
+    # to 8 % slower a second or two into the run — so everything here is compared with a plain loop of its own, not with
+    # `ms_per_step`): per-step p50 from one event pair per step, and
     # the step with the reference's mandatory 16N-byte position read-back (read_position_buffer after every step,
     # owPhysicsFluidSimulator.cpp:115) — started asynchronously so that the copy runs under the next step
     # (sph_read_position_async), timed INTERLEAVED with the same loop without it (plain, async, plain, async; 50 steps each), and
@@ -422,56 +473,6 @@ def rank_main(args):
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k3))
         p50_ms = per_step[len(per_step) // 2]
     beat("read-back pass done")
-
-    # second pass: the same steps with a HIP event pair around every stage (kept out of `value`)
-    stages_ms, stages_frac, roofline, sort_passes = {}, {}, None, None
-    if not args.no_stage_pass:
-        solver.set_stage_timing(True)
-        solver.reset_stage_times()
-        k2 = max(5, min(args.steps, 20))
-        for _ in range(k2):
-            stepper.step(it); it += 1
-        if decomposition is not None:
-            decomposition.finish()  # (collects the last asynchronous exchange: the local particle count)
-        st = solver.stage_times()
-        solver.set_stage_timing(False)
-        stages_ms = {k: round(ms / k2, 5) for k, (ms, cnt) in st.items() if cnt}
-        d_ms, d_cnt = st["density"]
-        n_local = solver.N  # particles this rank's density kernel processes per launch (incl. ghost layers when N > 1)
-        if d_cnt:
-            achieved = n_local * DENSITY_BYTES_PER_PARTICLE / (d_ms / d_cnt * 1e-3) / 1e9
-            roofline = {"kernel": "k_density (pcisph_computeDensity)", "bound": "hbm", "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "avg_launch_us": round(d_ms / d_cnt * 1e3, 2),
-                        "bytes_per_launch": n_local * DENSITY_BYTES_PER_PARTICLE}
-            # HBM bytes from the committed rocprofv3 PMC passes of this workload (profiles/README.md) — NOT measured in this
-            # run (counters cannot be read from inside the process), and only quoted while the kernel sources are the ones the
-            # passes were taken on
-            traffic_file = os.path.join(ROOT, "profiles", "density_traffic.json")
-            if os.path.exists(traffic_file) and world == 1:
-                tr = json.load(open(traffic_file))
-                entry = tr if tr.get("workload") == workload_name else tr.get("other_workloads", {}).get(workload_name)
-                if entry is not None:
-                    current = density_sources_sha()
-                    if tr.get("kernel_sources_sha256") in (None, current):
-                        roofline["traffic"] = entry.get("hbm_bytes_per_launch")
-                        roofline["traffic_source"] = "profiles/density_traffic.json (committed rocprofv3 PMC passes; not this run)"
-                    else:
-                        roofline["traffic_source"] = ("profiles/density_traffic.json is stale: measured on other kernel sources (%s..., now %s...)"
-                                                      % (tr["kernel_sources_sha256"][:12], current[:12]))
-        # per stage: algorithmic bytes of all its launches in one step / its time / 8 TB/s (pure-liquid scenes)
-        sort_passes = solver.step_sort_passes()
-        algo = dict(STAGE_ALGO_BYTES, sort=24 * sort_passes)  # 24 B per particle and radix pass (2 or 3 passes)
-        # (single domain only: in slab mode the stages are launched on different layer ranges and grouped differently)
-        stages_frac = {} if world > 1 else {k: round(n_local * algo[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                            for k, v in stages_ms.items() if k in algo and v > 0}
-        step_ms = sum(stages_ms.values())
-        if step_ms > 0 and world == 1:
-            stages_frac["whole_step_2600B"] = round(n_local * 2600.0 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            moved = sum(algo[k] for k in stages_ms if k in algo)
-            stages_frac["whole_step_bytes_moved"] = moved
-            stages_frac["whole_step_moved"] = round(n_local * moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    beat("stage pass done")
 
     # Multi-GPU sanity after the timed region (outside `value`): the ranks' owned sets must still partition the particles and
     # every owned particle must be finite — a silent halo failure would show here.
