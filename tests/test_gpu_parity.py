@@ -815,6 +815,28 @@ def test_async_position_read_back_overlaps_and_matches():
     assert scenes.bits_equal(sim.getPosition_cpp(), want[2])
 
 
+def test_async_position_read_back_with_membranes():
+    """The worm scene: positions are written by integrate AND by the membrane finalize pass of the same step; both must wait for a
+    read-back that is still in flight. Copies collected one step late equal the blocking reads of a twin run."""
+    sc = scenes.worm_scene()
+    N = sc["cfg"].particleCount
+    ref, hip = scenes.hip_for(sc), scenes.hip_for(scenes.worm_scene())
+    want = []
+    for it in range(4):
+        ref.step(it)
+        ref.updateMuscleActivityData(sphmi.muscle_signal(it))
+        want.append(ref.read_position_buffer().copy())
+    bufs = [np.empty((N, 4), np.float32), np.empty((N, 4), np.float32)]
+    for it in range(4):
+        hip.step(it)
+        hip.updateMuscleActivityData(sphmi.muscle_signal(it))
+        hip.read_position_buffer_async(bufs[it & 1])      # (waits for the copy of step it - 1 first)
+        if it:
+            assert scenes.bits_equal(bufs[(it - 1) & 1], want[it - 1]), "step %d" % (it - 1)
+    hip.wait_position_buffer()
+    assert scenes.bits_equal(bufs[1], want[3])
+
+
 def test_box_that_starts_below_zero_keeps_real_sort_keys():
     """Wide cell ids with xmin, ymin, zmin < 0 (no particle there): the compacted sort keys of the fused step are only monotone in
     the real cell ids while their clamps cannot bite, so such a box must sort the real keys — and still follow the oracle."""
